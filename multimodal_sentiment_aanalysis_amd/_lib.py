@@ -1,0 +1,108 @@
+"""ctypes binding of libmmsa_hip.so (C ABI: include/mmsa.h).
+
+The product path has no CPU fallback: if the shared library is missing, or a call returns a non-zero status,
+this module raises. PyTorch is used only for device memory, streams and autograd plumbing.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmmsa_hip.so")
+
+MMSA_F32, MMSA_BF16 = 0, 1
+GEMM_F32_SIMT, GEMM_BF16_MFMA, GEMM_BF16_SIMT = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+_STATUS = {1: "bad argument", 2: "kernel launch failure", 3: "unsupported shape"}
+
+
+class MmsaError(RuntimeError):
+    pass
+
+
+class ConvGeom(ctypes.Structure):
+    _fields_ = [
+        ("SH", ctypes.c_int32), ("SW", ctypes.c_int32), ("GH", ctypes.c_int32), ("GW", ctypes.c_int32),
+        ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("mul", ctypes.c_int32), ("kmul", ctypes.c_int32),
+        ("off", ctypes.c_int32), ("div", ctypes.c_int32), ("cper", ctypes.c_int32),
+        ("src_pix_stride", ctypes.c_int64),
+    ]
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p),
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("lda", ctypes.c_int64), ("ldb", ctypes.c_int64), ("ldc", ctypes.c_int64),
+        ("a_kmajor", ctypes.c_int32), ("b_kmajor", ctypes.c_int32), ("gather", ctypes.c_int32),
+        ("b_tap_stride", ctypes.c_int64),
+        ("geom", ConvGeom),
+        ("bias", ctypes.c_void_p), ("C2", ctypes.c_void_p), ("ldc2", ctypes.c_int64), ("act", ctypes.c_int32),
+        ("mul", ctypes.c_void_p), ("ldmul", ctypes.c_int64), ("add", ctypes.c_void_p), ("ldadd", ctypes.c_int64),
+        ("out_f32", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("split_k", ctypes.c_int32),
+        ("ws", ctypes.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises MmsaError when it has not been built (python __graft_entry__.py / make)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MmsaError(
+            f"{LIB_PATH} is missing: build it with `make -C multimodal_sentiment_aanalysis_amd/csrc` "
+            "(or __graft_entry__.build()). There is no CPU fallback for the product path.")
+    _lib = ctypes.CDLL(LIB_PATH)
+    _lib.mmsa_abi_version.restype = ctypes.c_int
+    for name in dir(_lib):
+        pass
+    _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    sz = ctypes.c_size_t
+    i32, i64, vp, f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_float
+    sig = {
+        "mmsa_gemm_ws_bytes": (sz, [i32, i32, i32]),
+        "mmsa_gemm": (ctypes.c_int, [ctypes.POINTER(GemmDesc), i32, vp]),
+        "mmsa_layernorm_fwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+        "mmsa_layernorm_bwd_ws_bytes": (sz, [i32]),
+        "mmsa_layernorm_bwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
+        "mmsa_colsum_ws_bytes": (sz, [i32]),
+        "mmsa_colsum": (ctypes.c_int, [i32, vp, i64, vp, i32, vp, i32, i32, vp]),
+        "mmsa_attention_bwd_ws_bytes": (sz, [i32, i32, i32]),
+        "mmsa_attention_fwd": (ctypes.c_int, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+        "mmsa_attention_bwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+def check(status, what):
+    if status != 0:
+        raise MmsaError(f"{what} failed: {_STATUS.get(status, status)}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return MMSA_F32
+    if t.dtype == torch.bfloat16:
+        return MMSA_BF16
+    raise MmsaError(f"unsupported storage dtype {t.dtype}")

@@ -1,0 +1,81 @@
+// extern "C" surface of libmmsa_hip.so (declared in include/mmsa.h). Thin: validates, converts the plain C
+// descriptors to the internal ones, and calls the launchers.
+#include "../../include/mmsa.h"
+#include "ops.h"
+
+static GemmParams to_params(const mmsa_gemm_desc* d) {
+  GemmParams p;
+  p.A = d->A; p.B = d->B; p.C = d->C;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+  p.a_kmajor = d->a_kmajor; p.b_kmajor = d->b_kmajor; p.gather = d->gather;
+  p.b_tap_stride = d->b_tap_stride;
+  const mmsa_conv_geom& s = d->geom;
+  ConvGeom& g = p.g;
+  g.SH = s.SH; g.SW = s.SW; g.GH = s.GH; g.GW = s.GW; g.KH = s.KH; g.KW = s.KW;
+  g.mul = s.mul; g.kmul = s.kmul; g.off = s.off; g.div = s.div; g.cper = s.cper;
+  g.src_pix_stride = s.src_pix_stride;
+  g.fd_gw = make_fastdiv(s.GW > 0 ? s.GW : 1);
+  g.fd_ghw = make_fastdiv(s.GH * s.GW > 0 ? s.GH * s.GW : 1);
+  g.fd_kw = make_fastdiv(s.KW > 0 ? s.KW : 1);
+  g.fd_cper = make_fastdiv(s.cper > 0 ? s.cper : 1);
+  p.bias = d->bias; p.C2 = d->C2; p.ldc2 = d->ldc2; p.act = d->act;
+  p.mul = d->mul; p.ldmul = d->ldmul; p.add = d->add; p.ldadd = d->ldadd;
+  p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.split_k = d->split_k; p.ws = d->ws;
+  p.zero_page = nullptr;
+  return p;
+}
+
+extern "C" {
+
+int mmsa_abi_version(void) { return 1; }
+
+size_t mmsa_gemm_ws_bytes(int32_t M, int32_t N, int32_t split_k) { return gemm_splitk_ws_bytes(M, N, split_k); }
+
+int mmsa_gemm(const mmsa_gemm_desc* d, int32_t impl, void* stream) {
+  if (!d || !d->A || !d->B || !d->C) return MMSA_ERR_ARG;
+  if (d->gather && (d->geom.GH <= 0 || d->geom.GW <= 0 || d->geom.KW <= 0 || d->geom.cper <= 0 || d->geom.div <= 0))
+    return MMSA_ERR_ARG;
+  const GemmParams p = to_params(d);
+  hipStream_t st = (hipStream_t)stream;
+  switch (impl) {
+    case MMSA_GEMM_F32_SIMT: return gemm_f32_launch(p, st);
+    case MMSA_GEMM_BF16_MFMA: return gemm_bf16_launch(p, st);
+    case MMSA_GEMM_BF16_SIMT: return gemm_bf16_simt_launch(p, st);
+    default: return MMSA_ERR_ARG;
+  }
+}
+
+int mmsa_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                       float* rstd, int32_t M, int32_t H, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || M <= 0) return MMSA_ERR_ARG;
+  return layernorm_fwd(dtype, x, gamma, beta, y, mean, rstd, M, H, eps, (hipStream_t)stream);
+}
+size_t mmsa_layernorm_bwd_ws_bytes(int32_t H) { return layernorm_bwd_ws_bytes(H); }
+int mmsa_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* mean, const float* rstd,
+                       const float* gamma, void* dx, float* dgamma, float* dbeta, int32_t accumulate, float* ws,
+                       int32_t M, int32_t H, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !ws || M <= 0) return MMSA_ERR_ARG;
+  return layernorm_bwd(dtype, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, accumulate, ws, M, H, (hipStream_t)stream);
+}
+
+size_t mmsa_colsum_ws_bytes(int32_t N) { return colsum_ws_bytes(N); }
+int mmsa_colsum(int32_t dtype, const void* x, int64_t ldx, float* out, int32_t accumulate, float* ws, int32_t M,
+                int32_t N, void* stream) {
+  if (!x || !out || !ws || M <= 0 || N <= 0) return MMSA_ERR_ARG;
+  return colsum(dtype, x, ldx, out, accumulate, ws, M, N, (hipStream_t)stream);
+}
+
+size_t mmsa_attention_bwd_ws_bytes(int32_t B, int32_t S, int32_t heads) { return attention_bwd_ws_bytes(B, S, heads); }
+int mmsa_attention_fwd(int32_t impl, const void* qkv, const float* mask, void* ctx, int32_t B, int32_t S, int32_t heads,
+                       int32_t head_dim, void* stream) {
+  if (!qkv || !ctx || B <= 0 || S <= 0 || heads <= 0) return MMSA_ERR_ARG;
+  return attention_fwd(impl, qkv, mask, ctx, B, S, heads, head_dim, (hipStream_t)stream);
+}
+int mmsa_attention_bwd(int32_t impl, const void* qkv, const float* mask, const void* dctx, void* dqkv, float* ws,
+                       int32_t B, int32_t S, int32_t heads, int32_t head_dim, void* stream) {
+  if (!qkv || !dctx || !dqkv || !ws || B <= 0 || S <= 0 || heads <= 0) return MMSA_ERR_ARG;
+  return attention_bwd(impl, qkv, mask, dctx, dqkv, ws, B, S, heads, head_dim, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the text+image hot path.
+// Everything here is written for wave64 / MFMA / LDS directly; there is no CUDA or multi-backend path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// status codes returned across the C ABI (include/mmsa.h)
+#define MMSA_OK 0
+#define MMSA_ERR_ARG 1
+#define MMSA_ERR_LAUNCH 2
+#define MMSA_ERR_UNSUPPORTED 3
+
+// storage dtype tags (activations / working weights); math is always fp32 accumulate
+#define MMSA_F32 0
+#define MMSA_BF16 1
+
+// epilogue activations
+#define MMSA_ACT_NONE 0
+#define MMSA_ACT_GELU 1
+#define MMSA_ACT_RELU 2
+#define MMSA_ACT_TANH 3
+#define MMSA_ACT_SIGMOID 4
+
+#define MMSA_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    hipError_t _e = hipGetLastError();                        \
+    if (_e != hipSuccess) return MMSA_ERR_LAUNCH;             \
+  } while (0)
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// round-trip through the storage type (identity for fp32): used where the bf16 path stores an
+// intermediate and re-reads it, so a fused kernel sees the same value as an unfused one.
+template <typename T> __device__ __forceinline__ float q_f32(float v) { return to_f32<T>(from_f32<T>(v)); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case MMSA_ACT_GELU: return gelu_erf(v);
+    case MMSA_ACT_RELU: return v > 0.f ? v : 0.f;
+    case MMSA_ACT_TANH: return tanhf(v);
+    case MMSA_ACT_SIGMOID: return sigmoidf_(v);
+    default: return v;
+  }
+}
+
+// wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block reduction over up to 16 waves; `red` is >=16 floats of LDS. Result valid in all threads.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// exact unsigned division by a runtime-constant divisor (n < 2^31, d < 2^31):
+// q = (n * magic) >> (31 + shift) with magic = floor(2^(31+shift)/d) + 1, shift = ceil(log2 d).
+struct FastDiv {
+  uint32_t magic;
+  uint32_t shift;
+  uint32_t d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shift = s;
+  f.magic = (uint32_t)(((1ull << (31 + s)) / d) + 1ull);
+  return f;
+}
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) {
+  return (uint32_t)(((uint64_t)n * (uint64_t)f.magic) >> (31 + f.shift));
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

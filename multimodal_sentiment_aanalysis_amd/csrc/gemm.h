@@ -1,0 +1,65 @@
+// GEMM descriptor shared by the bf16 MFMA kernel (gemm_mfma.hip) and the fp32 SIMT kernel (gemm_f32.hip).
+//
+//   C[M,N] = epilogue( sum_k opA[m][k] * opB[k][n] )
+//
+// Operand storage:
+//   a_kmajor = 0 : A stored [M][K], k contiguous, row stride lda        (activations in a forward Linear)
+//   a_kmajor = 1 : A stored [K][M], m contiguous, k-row stride lda      (dY^T in a weight-gradient GEMM)
+//   b_kmajor = 0 : B stored [N][K], k contiguous, row stride ldb        (nn.Linear weight [out,in])
+//   b_kmajor = 1 : B stored [K][N], n contiguous, k-row stride ldb      (weight in a data-gradient GEMM, X in wgrad)
+//
+// Implicit-GEMM convolution (NHWC activations, weights [Cout][KH][KW][Cin]) is expressed as a row gather:
+//   gather = 1 : A (k-contiguous) rows are pixels of a GH x GW grid; k = tap*cper + c; source pixel of (row, tap) is
+//                sy = y*mul + ky*kmul + off (same in x); when div > 1 the tap is valid only if sy % div == 0 and
+//                sy /= div. Invalid taps (padding, stride holes, rows >= M) read zeros.
+//                forward conv: mul = stride, kmul = +1, off = -pad, div = 1  (source = input activation)
+//                data grad   : mul = 1, kmul = -1, off = +pad, div = stride  (source = dY)
+//                With gather = 1 and b_kmajor = 1 the B row of k is (k % cper) * ldb + (k / cper) * b_tap_stride
+//                (weight [Cout][taps][Cin] read as [k = (tap, cout)][n = cin]).
+//   gather = 2 : B (k-major) rows (k) are output pixels, columns n = tap*cper + c; source as forward conv above
+//                (weight gradient: dW[cout][tap][cin] = sum_pixels dY[pixel][cout] * X[shifted pixel][cin]).
+#pragma once
+#include "common.h"
+
+struct ConvGeom {
+  int SH, SW;           // source spatial size
+  int GH, GW;           // row-space grid (rows -> (img, y, x))
+  int KH, KW;
+  int mul, kmul, off, div;
+  int cper;             // channels per tap along K (gather=1) or along N (gather=2)
+  long src_pix_stride;  // elements between consecutive source pixels
+  FastDiv fd_gw, fd_ghw, fd_kw, fd_cper;
+};
+
+struct GemmParams {
+  const void* A;
+  const void* B;
+  void* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  int a_kmajor, b_kmajor;
+  int gather;
+  long b_tap_stride;
+  ConvGeom g;
+  // epilogue: v = acc (+ bias[n]); C2 = v (optional, storage type); v = act(v); v *= gelu'(mul[m][n]) (optional);
+  //           v += add[m][n] (optional); C = v (storage type, or fp32 when out_f32; += when accumulate)
+  const float* bias;
+  void* C2;
+  long ldc2;
+  int act;
+  const void* mul;
+  long ldmul;
+  const void* add;
+  long ldadd;
+  int out_f32;
+  int accumulate;
+  // split-K: when split_k > 1 raw fp32 partials go to ws[split][M][N] and a second kernel reduces them into C
+  int split_k;
+  float* ws;
+  const void* zero_page;  // >= 64 bytes of zeros in device memory (source for padded taps)
+};
+
+int gemm_bf16_launch(const GemmParams& p, hipStream_t st);
+int gemm_f32_launch(const GemmParams& p, hipStream_t st);
+size_t gemm_splitk_ws_bytes(int M, int N, int split_k);
+const void* mmsa_zero_page();

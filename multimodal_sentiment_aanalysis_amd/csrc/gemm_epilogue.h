@@ -1,0 +1,74 @@
+// Fused GEMM epilogue shared by the MFMA kernel, the SIMT kernel and the split-K reducer.
+// Processes 4 consecutive columns n..n+3 of row m (N % 4 == 0 is required by the launchers).
+#pragma once
+#include "gemm.h"
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ f32x4 load(const float* p) { return *(const f32x4*)p; }
+  static __device__ __forceinline__ void store(float* p, f32x4 v) { *(f32x4*)p = v; }
+};
+template <> struct Vec4<bf16> {
+  static __device__ __forceinline__ f32x4 load(const bf16* p) {
+    bf16x4 t = *(const bf16x4*)p;
+    f32x4 v = {(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+    return v;
+  }
+  static __device__ __forceinline__ void store(bf16* p, f32x4 v) {
+    bf16x4 t = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *(bf16x4*)p = t;
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n, f32x4 v) {
+  if (p.bias) v += *(const f32x4*)(p.bias + n);
+  if (p.C2) Vec4<T>::store((T*)p.C2 + (long)m * p.ldc2 + n, v);
+  if (p.act != MMSA_ACT_NONE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+  }
+  if (p.mul) {
+    f32x4 x = Vec4<T>::load((const T*)p.mul + (long)m * p.ldmul + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(x[r]);
+  }
+  if (p.add) v += Vec4<T>::load((const T*)p.add + (long)m * p.ldadd + n);
+  if (p.out_f32) {
+    float* c = (float*)p.C + (long)m * p.ldc + n;
+    if (p.accumulate) v += *(const f32x4*)c;
+    *(f32x4*)c = v;
+  } else {
+    Vec4<T>::store((T*)p.C + (long)m * p.ldc + n, v);
+  }
+}
+
+// scalar form for shapes whose N (or a leading dimension) is not a multiple of 4 (the 3-class heads)
+template <typename T>
+__device__ __forceinline__ void gemm_epilogue1(const GemmParams& p, int m, int n, float v) {
+  if (p.bias) v += p.bias[n];
+  if (p.C2) ((T*)p.C2)[(long)m * p.ldc2 + n] = from_f32<T>(v);
+  if (p.act != MMSA_ACT_NONE) v = apply_act(v, p.act);
+  if (p.mul) v *= gelu_erf_grad(to_f32<T>(((const T*)p.mul)[(long)m * p.ldmul + n]));
+  if (p.add) v += to_f32<T>(((const T*)p.add)[(long)m * p.ldadd + n]);
+  if (p.out_f32) {
+    float* c = (float*)p.C + (long)m * p.ldc + n;
+    if (p.accumulate) v += *c;
+    *c = v;
+  } else {
+    ((T*)p.C)[(long)m * p.ldc + n] = from_f32<T>(v);
+  }
+}
+
+// Split-K second pass: sums the fp32 partial slabs and applies the epilogue.
+template <typename T>
+__global__ void gemm_splitk_reduce_kernel(GemmParams p) {
+  const long total4 = (long)p.M * p.N / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 4;
+    const int m = (int)(e / p.N), n = (int)(e - (long)m * p.N);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.split_k; ++s) v += *(const f32x4*)(p.ws + (long)s * p.M * p.N + e);
+    gemm_epilogue4<T>(p, m, n, v);
+  }
+}

@@ -1,0 +1,368 @@
+// bf16 MFMA GEMM for gfx950 (v_mfma_f32_16x16x32_bf16), fp32 accumulate.
+//
+// One 256-thread workgroup (4 waves, 2x2) computes a 128x128 tile of C; each wave owns 64x64 = 4x4 MFMA tiles.
+// K is consumed in steps of 64 through a double-buffered LDS image (2 x 32 KiB): the global loads of step t+1
+// are issued before the MFMAs of step t and written to the other LDS buffer after them (one barrier per step).
+//
+// Operands come in two storage forms (gemm.h): k-contiguous tiles are [128 rows][64 k] read with ds_read_b128
+// through a 16-byte XOR swizzle; k-major tiles are [64 k][128 cols] read with ds_read_b64_tr_b16 (the LDS
+// transpose read of CDNA4) through a 32-byte XOR swizzle, so NN (data gradient) and TN (weight gradient) GEMMs
+// need no transposed copies in HBM. The MFMA is issued with swapped operands (D = Bfrag x Afrag) so that each
+// lane ends up with 4 consecutive columns of one C row and the epilogue stores 8/16 bytes per lane.
+//
+// Implicit-GEMM convolution gathers are resolved per 16-byte chunk at staging time: an invalid chunk (padding,
+// stride hole, row/col/k past the end) is redirected to a page of zeros, so the main loop is branch-free.
+#include "gemm.h"
+#include "gemm_epilogue.h"
+
+#define TBM 128
+#define TBN 128
+#define TBK 64
+#define STAGE_BYTES 32768
+#define TILE_BYTES 16384
+
+__device__ uint4 g_mmsa_zero_page[32];  // 512 B of zeros
+
+const void* mmsa_zero_page() {
+  static const void* ptr = nullptr;
+  if (!ptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_mmsa_zero_page)) != hipSuccess) return nullptr;
+    ptr = p;
+  }
+  return ptr;
+}
+
+__device__ __forceinline__ int kmajor_swz(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+
+// LDS byte offset of 16-byte chunk kc (0..7) of row `row` in a k-contiguous tile [128][64]
+__device__ __forceinline__ int kc_off(int row, int kc) { return row * 128 + ((kc ^ (row & 7)) << 4); }
+// LDS byte offset of 16-byte chunk cc (0..15) of k-row `krow` in a k-major tile [64][128]
+__device__ __forceinline__ int km_off(int krow, int cc) {
+  return krow * 256 + ((((cc >> 1) ^ kmajor_swz(krow)) << 5) | ((cc & 1) << 4));
+}
+
+template <bool KM>
+__device__ __forceinline__ bf16x8 read_frag(const unsigned char* tile, int base_rc, int kk, int lane) {
+  const int r16 = lane & 15, g = lane >> 4;
+  if constexpr (!KM) {
+    const int row = base_rc + r16;
+    return *(const bf16x8*)(tile + kc_off(row, kk * 4 + g));
+  } else {
+    const int q = r16 >> 2, pp = r16 & 3;
+    const int col = base_rc + 4 * pp;
+    const int cc = col >> 3;
+    const int kb = kk * 32 + 8 * g;
+    const int a0 = km_off(kb + q, cc) + ((pp & 1) << 3);
+    const int a1 = km_off(kb + 4 + q, cc) + ((pp & 1) << 3);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + a1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+  }
+}
+
+struct RowPix {  // decomposed pixel of a gathered row
+  int img, yb, xb;  // img < 0: row invalid; yb = y*mul + off, xb = x*mul + off
+};
+
+__device__ __forceinline__ RowPix decompose_pixel(const ConvGeom& g, int m, int limit) {
+  RowPix r;
+  if (m >= limit) {
+    r.img = -1; r.yb = 0; r.xb = 0;
+    return r;
+  }
+  const uint32_t img = fd_div((uint32_t)m, g.fd_ghw);
+  const uint32_t rem = (uint32_t)m - img * (uint32_t)(g.GH * g.GW);
+  const uint32_t y = fd_div(rem, g.fd_gw);
+  const uint32_t x = rem - y * (uint32_t)g.GW;
+  r.img = (int)img;
+  r.yb = (int)y * g.mul + g.off;
+  r.xb = (int)x * g.mul + g.off;
+  return r;
+}
+
+// element offset of the source pixel for (row pixel, tap), or -1 when the tap is invalid
+__device__ __forceinline__ long tap_src(const ConvGeom& g, const RowPix& r, int ky, int kx) {
+  if (r.img < 0) return -1;
+  int sy = r.yb + ky * g.kmul, sx = r.xb + kx * g.kmul;
+  if (g.div > 1) {
+    if (sy < 0 || sx < 0) return -1;
+    if (g.div == 2) {
+      if ((sy | sx) & 1) return -1;
+      sy >>= 1; sx >>= 1;
+    } else {
+      if (sy % g.div || sx % g.div) return -1;
+      sy /= g.div; sx /= g.div;
+    }
+  }
+  if ((unsigned)sy >= (unsigned)g.SH || (unsigned)sx >= (unsigned)g.SW) return -1;
+  return (((long)r.img * g.SH + sy) * g.SW + sx) * g.src_pix_stride;
+}
+
+template <bool A_KM, bool B_KM, int GATHER>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- tile mapping: XCD-aware (blocks b and b+8 share an L2) + n-fastest order inside an XCD's contiguous chunk
+  const int ntn = (p.N + TBN - 1) / TBN, ntm = (p.M + TBM - 1) / TBM;
+  const int nblk = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tm = bid / ntn, tn = bid - tm * ntn;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+
+  // ---- K range of this split
+  int kbeg = 0, kend = p.K;
+  if (p.split_k > 1) {
+    const int steps = (p.K + TBK - 1) / TBK;
+    const int per = (steps + p.split_k - 1) / p.split_k;
+    kbeg = blockIdx.y * per * TBK;
+    kend = min(p.K, kbeg + per * TBK);
+  }
+  const int nk = kend > kbeg ? (kend - kbeg + TBK - 1) / TBK : 0;
+
+  const bf16* __restrict__ Ab = (const bf16*)p.A;
+  const bf16* __restrict__ Bb = (const bf16*)p.B;
+  const bf16* zp = (const bf16*)p.zero_page;
+
+  // ---- per-thread staging state (fixed over the K loop)
+  // k-contiguous tiles: chunk i -> row (tid>>3)+32i, 16-B chunk kc = tid&7
+  // k-major tiles     : chunk i -> k-row (tid>>4)+16i, 16-B chunk cc = tid&15
+  const int kc = tid & 7, rrow = tid >> 3;
+  const int cc = tid & 15, krow = tid >> 4;
+
+  long a_rowoff[4];  // !A_KM plain: element offset of the row (or -1)
+  RowPix a_pix[4];   // GATHER==1
+  long a_coloff = -1;  // A_KM: element offset of this thread's column chunk (or -1)
+  if constexpr (!A_KM) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + rrow + 32 * i;
+      if constexpr (GATHER == 1) a_pix[i] = decompose_pixel(p.g, m, p.M);
+      else a_rowoff[i] = m < p.M ? (long)m * p.lda : -1;
+    }
+  } else {
+    const int col = m0 + cc * 8;
+    a_coloff = col < p.M ? col : -1;
+  }
+  long b_rowoff[4];
+  long b_coloff = -1;
+  int b_ky = 0, b_kx = 0;  // GATHER==2: tap of this thread's column chunk
+  if constexpr (!B_KM) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + rrow + 32 * i;
+      b_rowoff[i] = n < p.N ? (long)n * p.ldb : -1;
+    }
+  } else {
+    const int col = n0 + cc * 8;
+    if constexpr (GATHER == 2) {
+      if (col < p.N) {
+        const uint32_t tap = fd_div((uint32_t)col, p.g.fd_cper);
+        b_coloff = col - (long)tap * p.g.cper;
+        b_ky = (int)fd_div(tap, p.g.fd_kw);
+        b_kx = (int)tap - b_ky * p.g.KW;
+      }
+    } else {
+      b_coloff = col < p.N ? col : -1;
+    }
+  }
+
+  bf16x8 ra[4], rb[4];
+
+  auto load_tiles = [&](int k0) {
+    // ---------------- A
+    if constexpr (!A_KM) {
+      const int kcol = k0 + kc * 8;
+      const bool kvalid = kcol < kend;
+      if constexpr (GATHER == 1) {
+        const uint32_t tap = fd_div((uint32_t)k0, p.g.fd_cper);
+        const int c0 = k0 - (int)tap * p.g.cper;
+        const int ky = (int)fd_div(tap, p.g.fd_kw), kx = (int)tap - ky * p.g.KW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const long s = tap_src(p.g, a_pix[i], ky, kx);
+          const bf16* src = (s >= 0 && kvalid) ? Ab + s + c0 + kc * 8 : zp;
+          ra[i] = *(const bf16x8*)src;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bf16* src = (a_rowoff[i] >= 0 && kvalid) ? Ab + a_rowoff[i] + kcol : zp;
+          ra[i] = *(const bf16x8*)src;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + krow + 16 * i;
+        const bf16* src = (a_coloff >= 0 && k < kend) ? Ab + (long)k * p.lda + a_coloff : zp;
+        ra[i] = *(const bf16x8*)src;
+      }
+    }
+    // ---------------- B
+    if constexpr (!B_KM) {
+      const int kcol = k0 + kc * 8;
+      const bool kvalid = kcol < kend;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16* src = (b_rowoff[i] >= 0 && kvalid) ? Bb + b_rowoff[i] + kcol : zp;
+        rb[i] = *(const bf16x8*)src;
+      }
+    } else if constexpr (GATHER == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + krow + 16 * i;
+        const RowPix px = decompose_pixel(p.g, k, kend);
+        const long s = tap_src(p.g, px, b_ky, b_kx);
+        const bf16* src = (s >= 0 && b_coloff >= 0) ? Bb + s + b_coloff : zp;
+        rb[i] = *(const bf16x8*)src;
+      }
+    } else {
+      long tapoff = 0;
+      int kbase = k0;
+      if constexpr (GATHER == 1) {  // weight [cout][tap][cin] read as rows k = (tap, cout)
+        const uint32_t tap = fd_div((uint32_t)k0, p.g.fd_cper);
+        kbase = k0 - (int)tap * p.g.cper;
+        tapoff = (long)tap * p.b_tap_stride;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + krow + 16 * i;
+        const bf16* src = (b_coloff >= 0 && k < kend) ? Bb + (long)(kbase + krow + 16 * i) * p.ldb + tapoff + b_coloff : zp;
+        rb[i] = *(const bf16x8*)src;
+      }
+    }
+  };
+
+  auto store_tiles = [&](int stage) {
+    unsigned char* sa = smem + stage * STAGE_BYTES;
+    unsigned char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (!A_KM) *(bf16x8*)(sa + kc_off(rrow + 32 * i, kc)) = ra[i];
+      else *(bf16x8*)(sa + km_off(krow + 16 * i, cc)) = ra[i];
+      if constexpr (!B_KM) *(bf16x8*)(sb + kc_off(rrow + 32 * i, kc)) = rb[i];
+      else *(bf16x8*)(sb + km_off(krow + 16 * i, cc)) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    load_tiles(kbeg);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_tiles(kbeg + (kt + 1) * TBK);
+    const unsigned char* sa = smem + cur * STAGE_BYTES;
+    const unsigned char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KM>(sa, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KM>(sb, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds C[m = ..+(lane&15)][n = ..+4*(lane>>4)+r]
+  const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + r16;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * g;
+      if (n >= p.N) continue;
+      if (p.split_k > 1) {
+        *(f32x4*)(p.ws + ((long)blockIdx.y * p.M + m) * p.N + n) = acc[i][j];
+      } else {
+        gemm_epilogue4<bf16>(p, m, n, acc[i][j]);
+      }
+    }
+  }
+}
+
+size_t gemm_splitk_ws_bytes(int M, int N, int split_k) { return split_k > 1 ? (size_t)split_k * M * N * sizeof(float) : 0; }
+
+template <bool A_KM, bool B_KM, int GATHER>
+static int launch_variant(const GemmParams& p, hipStream_t st) {
+  const int ntm = cdiv(p.M, TBM), ntn = cdiv(p.N, TBN);
+  dim3 grid(ntm * ntn, p.split_k > 1 ? p.split_k : 1, 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<A_KM, B_KM, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        2 * STAGE_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_kernel<A_KM, B_KM, GATHER>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
+  MMSA_CHECK_LAUNCH();
+  if (p.split_k > 1) {
+    const long total4 = (long)p.M * p.N / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel<bf16>, dim3(blocks), dim3(256), 0, st, p);
+    MMSA_CHECK_LAUNCH();
+  }
+  return MMSA_OK;
+}
+
+int gemm_bf16_launch(const GemmParams& pin, hipStream_t st) {
+  GemmParams p = pin;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MMSA_ERR_ARG;
+  if (p.N % 4) return MMSA_ERR_ARG;
+  // every 16-byte chunk must be wholly valid or wholly out of range
+  if (p.K % 8 && !(p.a_kmajor && p.b_kmajor)) return MMSA_ERR_ARG;
+  if (p.a_kmajor && (p.M % 8)) return MMSA_ERR_ARG;
+  if (p.b_kmajor && (p.N % 8)) return MMSA_ERR_ARG;
+  if ((p.lda % 8) || (p.ldb % 8)) return MMSA_ERR_ARG;
+  if (p.gather && (p.g.cper % 8)) return MMSA_ERR_ARG;
+  if (p.gather == 1 && (p.g.cper % TBK)) return MMSA_ERR_ARG;  // a K step must stay inside one tap
+  if (p.split_k > 1 && !p.ws) return MMSA_ERR_ARG;
+  if (p.split_k < 1) p.split_k = 1;
+  p.zero_page = mmsa_zero_page();
+  if (!p.zero_page) return MMSA_ERR_LAUNCH;
+  if (p.gather == 0) {
+    if (!p.a_kmajor && !p.b_kmajor) return launch_variant<false, false, 0>(p, st);
+    if (!p.a_kmajor && p.b_kmajor) return launch_variant<false, true, 0>(p, st);
+    if (p.a_kmajor && p.b_kmajor) return launch_variant<true, true, 0>(p, st);
+    return launch_variant<true, false, 0>(p, st);
+  }
+  if (p.gather == 1) {
+    if (p.a_kmajor) return MMSA_ERR_ARG;
+    if (!p.b_kmajor) return launch_variant<false, false, 1>(p, st);
+    return launch_variant<false, true, 1>(p, st);
+  }
+  if (p.gather == 2) {
+    if (!(p.a_kmajor && p.b_kmajor)) return MMSA_ERR_ARG;
+    return launch_variant<true, true, 2>(p, st);
+  }
+  return MMSA_ERR_ARG;
+}

@@ -1,0 +1,146 @@
+// SIMT (VALU fma) GEMM with the same descriptor as the MFMA kernel, templated on the storage type.
+//
+// Two uses: (1) storage = fp32: the exact-fp32 execution mode of the whole path (parity against the fp32 CPU
+// oracle at 1e-3 / 1e-4) and the small fp32 Linears of the fusion head; (2) storage = bf16: an independent
+// on-device cross-check of the MFMA kernel (same inputs, same fp32 accumulation, different code).
+// 64x64 tile, 256 threads, 4x4 outputs per thread, K step 16. Addressing is per element and fully general
+// (every gather mode of gemm.h), which is what makes it a useful checker; it is not a performance kernel.
+#include "gemm.h"
+#include "gemm_epilogue.h"
+
+#define SBM 64
+#define SBN 64
+#define SBK 16
+
+__device__ __forceinline__ long simt_tap_src(const ConvGeom& g, int pix, int ky, int kx) {
+  const int ghw = g.GH * g.GW;
+  const int img = pix / ghw, rem = pix - img * ghw;
+  const int y = rem / g.GW, x = rem - y * g.GW;
+  int sy = y * g.mul + g.off + ky * g.kmul, sx = x * g.mul + g.off + kx * g.kmul;
+  if (g.div > 1) {
+    if (sy < 0 || sx < 0 || sy % g.div || sx % g.div) return -1;
+    sy /= g.div; sx /= g.div;
+  }
+  if (sy < 0 || sx < 0 || sy >= g.SH || sx >= g.SW) return -1;
+  return (((long)img * g.SH + sy) * g.SW + sx) * g.src_pix_stride;
+}
+
+template <typename T>
+__device__ __forceinline__ float simt_load_a(const GemmParams& p, int m, int k, int kend) {
+  if (m >= p.M || k >= kend) return 0.f;
+  const T* A = (const T*)p.A;
+  if (p.gather == 1) {
+    const int tap = k / p.g.cper, c = k - tap * p.g.cper;
+    const int ky = tap / p.g.KW, kx = tap - ky * p.g.KW;
+    const long s = simt_tap_src(p.g, m, ky, kx);
+    return s < 0 ? 0.f : to_f32<T>(A[s + c]);
+  }
+  return to_f32<T>(p.a_kmajor ? A[(long)k * p.lda + m] : A[(long)m * p.lda + k]);
+}
+
+template <typename T>
+__device__ __forceinline__ float simt_load_b(const GemmParams& p, int k, int n, int kend) {
+  if (n >= p.N || k >= kend) return 0.f;
+  const T* B = (const T*)p.B;
+  if (p.gather == 2) {
+    const int tap = n / p.g.cper, c = n - tap * p.g.cper;
+    const int ky = tap / p.g.KW, kx = tap - ky * p.g.KW;
+    const long s = simt_tap_src(p.g, k, ky, kx);
+    return s < 0 ? 0.f : to_f32<T>(B[s + c]);
+  }
+  if (p.gather == 1 && p.b_kmajor) {
+    const int tap = k / p.g.cper, c = k - tap * p.g.cper;
+    return to_f32<T>(B[(long)c * p.ldb + (long)tap * p.b_tap_stride + n]);
+  }
+  return to_f32<T>(p.b_kmajor ? B[(long)k * p.ldb + n] : B[(long)n * p.ldb + k]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_simt_kernel(GemmParams p) {
+  __shared__ float As[SBK][SBM + 4];
+  __shared__ float Bs[SBK][SBN + 4];
+  const int tid = threadIdx.x;
+  const int ntn = (p.N + SBN - 1) / SBN;
+  const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
+  const int m0 = tm * SBM, n0 = tn * SBN;
+  int kbeg = 0, kend = p.K;
+  if (p.split_k > 1) {
+    const int steps = (p.K + SBK - 1) / SBK;
+    const int per = (steps + p.split_k - 1) / p.split_k;
+    kbeg = blockIdx.y * per * SBK;
+    kend = min(p.K, kbeg + per * SBK);
+  }
+  const int ty = tid >> 4, tx = tid & 15;  // thread computes rows ty*4.., cols tx*4..
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int k0 = kbeg; k0 < kend; k0 += SBK) {
+    // 64x16 elements per operand, 4 per thread. Pick the thread->element map so global reads are coalesced
+    // along the contiguous dimension of each storage form.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      int mm, kk;
+      if (p.a_kmajor) { mm = e & 63; kk = e >> 6; } else { kk = e & 15; mm = e >> 4; }
+      As[kk][mm] = simt_load_a<T>(p, m0 + mm, k0 + kk, kend);
+      int nn, kb;
+      if (p.b_kmajor) { nn = e & 63; kb = e >> 6; } else { kb = e & 15; nn = e >> 4; }
+      Bs[kb][nn] = simt_load_b<T>(p, k0 + kb, n0 + nn, kend);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < SBK; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  const bool vec_ok = !(p.N & 3) && !(p.ldc & 3) && !(p.ldc2 & 3) && !(p.ldmul & 3) && !(p.ldadd & 3);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    const int n = n0 + tx * 4;
+    if (m >= p.M || n >= p.N) continue;
+    if (vec_ok) {
+      f32x4 v = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+      if (p.split_k > 1) *(f32x4*)(p.ws + ((long)blockIdx.y * p.M + m) * p.N + n) = v;
+      else gemm_epilogue4<T>(p, m, n, v);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j < p.N) gemm_epilogue1<T>(p, m, n + j, acc[i][j]);
+    }
+  }
+}
+
+template <typename T>
+static int simt_launch(const GemmParams& pin, hipStream_t st) {
+  GemmParams p = pin;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MMSA_ERR_ARG;
+  if (p.split_k < 1) p.split_k = 1;
+  if (p.split_k > 1 && (!p.ws || (p.N % 4))) return MMSA_ERR_ARG;
+  dim3 grid(cdiv(p.M, SBM) * cdiv(p.N, SBN), p.split_k, 1);
+  hipLaunchKernelGGL(gemm_simt_kernel<T>, grid, dim3(256), 0, st, p);
+  MMSA_CHECK_LAUNCH();
+  if (p.split_k > 1) {
+    const long total4 = (long)p.M * p.N / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, st, p);
+    MMSA_CHECK_LAUNCH();
+  }
+  return MMSA_OK;
+}
+
+int gemm_f32_launch(const GemmParams& p, hipStream_t st) { return simt_launch<float>(p, st); }
+int gemm_bf16_simt_launch(const GemmParams& p, hipStream_t st) { return simt_launch<bf16>(p, st); }

@@ -1,0 +1,311 @@
+// HBM-bound row/column kernels of the BERT side: LayerNorm fwd/bwd (with the residual add done by the GEMM
+// epilogue upstream), embedding gather + LayerNorm, embedding scatter, column sums (bias gradients) and the
+// deterministic two-stage column-partial finalizer. All activations are [rows][H] with H % 4 == 0; one wave
+// handles one row with 4-element vector accesses, statistics in fp32.
+#include "common.h"
+#include "gemm_epilogue.h"  // Vec4
+#include "ops.h"
+
+// NCH = per-lane 4-element chunks (template): 1 -> H <= 256, 4 -> H <= 1024, 8 -> H <= 2048
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int M, int H, float eps) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nch = H >> 2;
+  for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
+    const T* xr = x + (long)row * H;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        v[c] = Vec4<T>::load(xr + ch * 4);
+        s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+      }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[c][e] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+    T* yr = y + (long)row * H;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        const f32x4 g = *(const f32x4*)(gamma + ch * 4), b = *(const f32x4*)(beta + ch * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
+        Vec4<T>::store(yr + ch * 4, o);
+      }
+    }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma ; per-block partial dgamma/dbeta -> part[blk][2][H]
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, T* __restrict__ dx,
+                                                            float* __restrict__ part, int M, int H) {
+  extern __shared__ float lds[];  // [4 waves][2][H]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nch = H >> 2;
+  f32x4 ag[NCH], ab[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) { ag[c] = f32x4{0, 0, 0, 0}; ab[c] = f32x4{0, 0, 0, 0}; }
+  for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
+    const T* xr = x + (long)row * H;
+    const T* dr = dy + (long)row * H;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[NCH], gg[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        const f32x4 xv = Vec4<T>::load(xr + ch * 4), dv = Vec4<T>::load(dr + ch * 4);
+        const f32x4 g = *(const f32x4*)(gamma + ch * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[c][e] = (xv[e] - mu) * rs;
+          gg[c][e] = dv[e] * g[e];
+          s1 += gg[c][e];
+          s2 += gg[c][e] * xh[c][e];
+          ag[c][e] += dv[e] * xh[c][e];
+          ab[c][e] += dv[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+    T* oxr = dx + (long)row * H;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gg[c][e] - s1 - xh[c][e] * s2);
+        Vec4<T>::store(oxr + ch * 4, o);
+      }
+    }
+  }
+  // combine the 4 waves of the block, then write the block partial
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      *(f32x4*)(lds + (w * 2 + 0) * H + ch * 4) = ag[c];
+      *(f32x4*)(lds + (w * 2 + 1) * H + ch * 4) = ab[c];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * H; i += blockDim.x) {
+    const int which = i / H, col = i - which * H;
+    float t = 0.f;
+    for (int ww = 0; ww < 4; ++ww) t += lds[(ww * 2 + which) * H + col];
+    part[((long)blockIdx.x * 2 + which) * H + col] = t;
+  }
+}
+
+// out[j] (+)= scale * sum_b part[b * stride + j]  for j in [0, n)   (fixed order: bitwise reproducible)
+__global__ void partial_finalize_kernel(const float* __restrict__ part, int nblk, long stride, int n,
+                                        float* __restrict__ out, int accumulate, float scale) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float t = 0.f;
+  for (int b = 0; b < nblk; ++b) t += part[(long)b * stride + j];
+  t *= scale;
+  out[j] = accumulate ? out[j] + t : t;
+}
+
+int partial_finalize(const float* part, int nblk, long stride, int n, float* out, int accumulate, float scale,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(partial_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, nblk, stride, n, out,
+                     accumulate, scale);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+#define LN_DISPATCH(KERNEL, T, H, ...)                                                           \
+  do {                                                                                           \
+    if ((H) <= 256) hipLaunchKernelGGL((KERNEL<T, 1>), __VA_ARGS__);                              \
+    else if ((H) <= 1024) hipLaunchKernelGGL((KERNEL<T, 4>), __VA_ARGS__);                        \
+    else hipLaunchKernelGGL((KERNEL<T, 8>), __VA_ARGS__);                                         \
+  } while (0)
+
+int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                  int M, int H, float eps, hipStream_t st) {
+  if (H % 4 || H > 2048) return MMSA_ERR_ARG;
+  const int grid = min(cdiv(M, 4), 4096);
+  if (dtype == MMSA_BF16)
+    LN_DISPATCH(layernorm_fwd_kernel, bf16, H, dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, mean,
+                rstd, M, H, eps);
+  else
+    LN_DISPATCH(layernorm_fwd_kernel, float, H, dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y,
+                mean, rstd, M, H, eps);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+#define LN_BWD_BLOCKS 256
+size_t layernorm_bwd_ws_bytes(int H) { return (size_t)LN_BWD_BLOCKS * 2 * H * sizeof(float); }
+
+int layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                  void* dx, float* dgamma, float* dbeta, int accumulate, float* ws, int M, int H, hipStream_t st) {
+  if (H % 4 || H > 2048) return MMSA_ERR_ARG;
+  const int grid = min(cdiv(M, 4), LN_BWD_BLOCKS);
+  const size_t lds = (size_t)8 * H * sizeof(float);
+  if (dtype == MMSA_BF16)
+    LN_DISPATCH(layernorm_bwd_kernel, bf16, H, dim3(grid), dim3(256), lds, st, (const bf16*)dy, (const bf16*)x, mean, rstd,
+                gamma, (bf16*)dx, ws, M, H);
+  else
+    LN_DISPATCH(layernorm_bwd_kernel, float, H, dim3(grid), dim3(256), lds, st, (const float*)dy, (const float*)x, mean,
+                rstd, gamma, (float*)dx, ws, M, H);
+  MMSA_CHECK_LAUNCH();
+  // partial layout is [blk][2][H]
+  int rc = partial_finalize(ws, grid, 2L * H, H, dgamma, accumulate, 1.f, st);
+  if (rc) return rc;
+  return partial_finalize(ws + H, grid, 2L * H, H, dbeta, accumulate, 1.f, st);
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// part[chunk][N] = sum over the chunk's rows of x[row][:]; finalize adds the chunks in order (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long ldx, float* __restrict__ part,
+                                                             int M, int N, int rows_per_chunk) {
+  const int col = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (col >= N) return;
+  const int r0 = blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  f32x4 a = {0, 0, 0, 0};
+  for (int r = r0; r < r1; ++r) a += Vec4<T>::load(x + (long)r * ldx + col);
+  *(f32x4*)(part + (long)blockIdx.x * N + col) = a;
+}
+
+#define COLSUM_CHUNKS 128
+size_t colsum_ws_bytes(int N) { return (size_t)COLSUM_CHUNKS * N * sizeof(float); }
+
+int colsum(int dtype, const void* x, long ldx, float* out, int accumulate, float* ws, int M, int N, hipStream_t st) {
+  if (N % 4 || ldx % 4) return MMSA_ERR_ARG;
+  const int rpc = cdiv(M, COLSUM_CHUNKS);
+  const int chunks = cdiv(M, rpc);
+  dim3 grid(chunks, cdiv(N, 1024));
+  if (dtype == MMSA_BF16)
+    hipLaunchKernelGGL(colsum_partial_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, ldx, ws, M, N, rpc);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, ws, M, N, rpc);
+  MMSA_CHECK_LAUNCH();
+  return partial_finalize(ws, chunks, N, N, out, accumulate, 1.f, st);
+}
+
+// ------------------------------------------------------------------------------------------------ embeddings
+// e[m][:] = word[ids[m]] + pos[m % S] + type[0]   (HF BertEmbeddings with default position / token-type ids)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_gather_kernel(const long long* __restrict__ ids, const T* __restrict__ word,
+                                                           const T* __restrict__ pos, const T* __restrict__ type,
+                                                           T* __restrict__ e, int M, int S, int H, int vocab) {
+  const int nch = H >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * nch; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / nch), ch = (int)(i - (long)m * nch);
+    long long id = ids[m];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    const f32x4 w = Vec4<T>::load(word + id * H + ch * 4);
+    const f32x4 p = Vec4<T>::load(pos + (long)(m % S) * H + ch * 4);
+    const f32x4 t = Vec4<T>::load(type + ch * 4);
+    Vec4<T>::store(e + (long)m * H + ch * 4, w + p + t);
+  }
+}
+
+int embed_gather(int dtype, const long long* ids, const void* word, const void* pos, const void* type, void* e, int M,
+                 int S, int H, int vocab, hipStream_t st) {
+  if (H % 4) return MMSA_ERR_ARG;
+  const long total = (long)M * (H / 4);
+  const int grid = (int)min((total + 255) / 256, (long)4096);
+  if (dtype == MMSA_BF16)
+    hipLaunchKernelGGL(embed_gather_kernel<bf16>, dim3(grid), dim3(256), 0, st, ids, (const bf16*)word, (const bf16*)pos,
+                       (const bf16*)type, (bf16*)e, M, S, H, vocab);
+  else
+    hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(grid), dim3(256), 0, st, ids, (const float*)word,
+                       (const float*)pos, (const float*)type, (float*)e, M, S, H, vocab);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+// dword[ids[m]] += de[m] (fp32 atomics: rows collide only for repeated tokens); dpos[s] (+)= sum_b de[b*S+s]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_scatter_word_kernel(const long long* __restrict__ ids,
+                                                                 const T* __restrict__ de, float* __restrict__ dword,
+                                                                 int M, int H, int vocab) {
+  const int nch = H >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * nch; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / nch), ch = (int)(i - (long)m * nch);
+    long long id = ids[m];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    const f32x4 g = Vec4<T>::load(de + (long)m * H + ch * 4);
+    float* dst = dword + id * H + ch * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dst + e, g[e]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_pos_grad_kernel(const T* __restrict__ de, float* __restrict__ dpos, int B,
+                                                             int S, int H, int accumulate) {
+  const int nch = H >> 2;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)S * nch) return;
+  const int s = (int)(i / nch), ch = (int)(i - (long)s * nch);
+  f32x4 a = {0, 0, 0, 0};
+  for (int b = 0; b < B; ++b) a += Vec4<T>::load(de + ((long)b * S + s) * H + ch * 4);
+  float* dst = dpos + (long)s * H + ch * 4;
+  if (accumulate) a += *(const f32x4*)dst;
+  *(f32x4*)dst = a;
+}
+
+int embed_backward(int dtype, const long long* ids, const void* de, float* dword, float* dpos, float* dtype0,
+                   int accumulate, float* ws, int B, int S, int H, int vocab, int maxpos, hipStream_t st) {
+  if (H % 4) return MMSA_ERR_ARG;
+  const int M = B * S;
+  if (!accumulate) {
+    if (hipMemsetAsync(dword, 0, (size_t)vocab * H * sizeof(float), st) != hipSuccess) return MMSA_ERR_LAUNCH;
+    if (maxpos > S &&
+        hipMemsetAsync(dpos + (long)S * H, 0, (size_t)(maxpos - S) * H * sizeof(float), st) != hipSuccess)
+      return MMSA_ERR_LAUNCH;
+  }
+  const long total = (long)M * (H / 4);
+  const int grid = (int)min((total + 255) / 256, (long)4096);
+  const int pgrid = cdiv((long)S * (H / 4), 256);
+  if (dtype == MMSA_BF16) {
+    hipLaunchKernelGGL(embed_scatter_word_kernel<bf16>, dim3(grid), dim3(256), 0, st, ids, (const bf16*)de, dword, M, H,
+                       vocab);
+    hipLaunchKernelGGL(embed_pos_grad_kernel<bf16>, dim3(pgrid), dim3(256), 0, st, (const bf16*)de, dpos, B, S, H,
+                       accumulate);
+  } else {
+    hipLaunchKernelGGL(embed_scatter_word_kernel<float>, dim3(grid), dim3(256), 0, st, ids, (const float*)de, dword, M, H,
+                       vocab);
+    hipLaunchKernelGGL(embed_pos_grad_kernel<float>, dim3(pgrid), dim3(256), 0, st, (const float*)de, dpos, B, S, H,
+                       accumulate);
+  }
+  MMSA_CHECK_LAUNCH();
+  // token-type row 0 receives every token's gradient (default token_type_ids = 0); row 1 gets none
+  return colsum(dtype, de, H, dtype0, accumulate, ws, M, H, st);
+}

@@ -1,0 +1,124 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per `mmsa_*` entry point).
+
+They take torch tensors only to obtain device pointers, shapes and the current HIP stream; all arithmetic
+happens in libmmsa_hip.so. Used by the autograd Functions in this package and by the GPU parity tests.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, GEMM_BF16_MFMA, GEMM_BF16_SIMT,
+                   GEMM_F32_SIMT, ConvGeom, GemmDesc, check, dtype_code, ptr, stream_ptr)
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="ws"):
+    """Grow-only scratch buffer per (device, tag); never shrinks, so steady-state steps allocate nothing."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def default_impl(t):
+    return GEMM_BF16_MFMA if t.dtype == torch.bfloat16 else GEMM_F32_SIMT
+
+
+def conv_geom(SH, SW, GH, GW, KH, KW, mul, kmul, off, div, cper, src_pix_stride):
+    g = ConvGeom()
+    g.SH, g.SW, g.GH, g.GW, g.KH, g.KW = SH, SW, GH, GW, KH, KW
+    g.mul, g.kmul, g.off, g.div, g.cper, g.src_pix_stride = mul, kmul, off, div, cper, src_pix_stride
+    return g
+
+
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, gather=0, geom=None, b_tap_stride=0, bias=None,
+         C2=None, ldc2=0, act=ACT_NONE, mul=None, ldmul=0, add=None, ldadd=0, out_f32=0, accumulate=0, split_k=1,
+         impl=None):
+    """C[M,N] = epilogue(opA @ opB); see include/mmsa.h (mmsa_gemm). A/B/C are tensors (any view; pointers are used)."""
+    L = _lib.load()
+    d = GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.a_kmajor, d.b_kmajor, d.gather = a_kmajor, b_kmajor, gather
+    d.b_tap_stride = b_tap_stride
+    if geom is not None:
+        d.geom = geom
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.C2 = C2.data_ptr() if C2 is not None else None
+    d.ldc2 = ldc2
+    d.act = act
+    d.mul = mul.data_ptr() if mul is not None else None
+    d.ldmul = ldmul
+    d.add = add.data_ptr() if add is not None else None
+    d.ldadd = ldadd
+    d.out_f32, d.accumulate, d.split_k = out_f32, accumulate, split_k
+    if split_k > 1:
+        ws = workspace(L.mmsa_gemm_ws_bytes(M, N, split_k), A.device, "splitk")
+        d.ws = ws.data_ptr()
+    if impl is None:
+        impl = default_impl(A)
+    check(L.mmsa_gemm(ctypes.byref(d), impl, stream_ptr()), "mmsa_gemm")
+    return C
+
+
+def layernorm_fwd(x, gamma, beta, eps):
+    L = _lib.load()
+    M, H = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(L.mmsa_layernorm_fwd(dtype_code(x), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, H,
+                               eps, stream_ptr()), "mmsa_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, accumulate=0):
+    L = _lib.load()
+    M, H = x.shape
+    dx = torch.empty_like(x)
+    if dgamma is None:
+        dgamma = torch.empty(H, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(H, dtype=torch.float32, device=x.device)
+        accumulate = 0
+    ws = workspace(L.mmsa_layernorm_bwd_ws_bytes(H), x.device, "ln")
+    check(L.mmsa_layernorm_bwd(dtype_code(x), ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx), ptr(dgamma),
+                               ptr(dbeta), accumulate, ptr(ws), M, H, stream_ptr()), "mmsa_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def colsum(x, out=None, accumulate=0):
+    L = _lib.load()
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+        accumulate = 0
+    ws = workspace(L.mmsa_colsum_ws_bytes(N), x.device, "colsum")
+    check(L.mmsa_colsum(dtype_code(x), ptr(x), x.stride(0), ptr(out), accumulate, ptr(ws), M, N, stream_ptr()),
+          "mmsa_colsum")
+    return out
+
+
+def attention_fwd(qkv, mask, B, S, heads, impl=None):
+    L = _lib.load()
+    if impl is None:
+        impl = default_impl(qkv)
+    ctx = torch.empty(B * S, heads * 64, dtype=qkv.dtype, device=qkv.device)
+    check(L.mmsa_attention_fwd(impl, ptr(qkv), ptr(mask), ptr(ctx), B, S, heads, 64, stream_ptr()),
+          "mmsa_attention_fwd")
+    return ctx
+
+
+def attention_bwd(qkv, mask, dctx, B, S, heads, impl=None):
+    L = _lib.load()
+    if impl is None:
+        impl = default_impl(qkv)
+    dqkv = torch.empty_like(qkv)
+    ws = workspace(L.mmsa_attention_bwd_ws_bytes(B, S, heads), qkv.device, "attn")
+    check(L.mmsa_attention_bwd(impl, ptr(qkv), ptr(mask), ptr(dctx), ptr(dqkv), ptr(ws), B, S, heads, 64,
+                               stream_ptr()), "mmsa_attention_bwd")
+    return dqkv

@@ -1,0 +1,220 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (ctypes).
+
+References are computed on the CPU in float64 from the same (already storage-rounded) inputs, so the only
+differences are accumulation order and the final rounding to the storage type.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from multimodal_sentiment_aanalysis_amd import kernels as K
+from multimodal_sentiment_aanalysis_amd._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH, GEMM_BF16_MFMA,
+                                                     GEMM_BF16_SIMT, GEMM_F32_SIMT)
+
+IMPLS = [(GEMM_F32_SIMT, torch.float32), (GEMM_BF16_MFMA, torch.bfloat16), (GEMM_BF16_SIMT, torch.bfloat16)]
+
+
+def rnd(shape, dtype, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def assert_close(got, ref, dtype, what, k=1):
+    got = got.detach().cpu().double()
+    ref = ref.double()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item() / scale
+    tol = 1.2e-2 if dtype == torch.bfloat16 else 2e-5
+    assert err < tol, f"{what}: rel-to-max err {err:.3e} >= {tol}"
+
+
+@pytest.mark.parametrize("impl,dtype", IMPLS)
+@pytest.mark.parametrize("M,N,Kd", [(256, 256, 128), (300, 136, 72), (128, 64, 64), (1024, 768, 768), (77, 260, 200)])
+def test_gemm_nt(dev, impl, dtype, M, N, Kd):
+    A = rnd((M, Kd), dtype, dev, 1)
+    B = rnd((N, Kd), dtype, dev, 2)
+    C = torch.empty(M, N, dtype=dtype, device=dev)
+    K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, impl=impl)
+    assert_close(C, A.cpu().double() @ B.cpu().double().T, dtype, "NT")
+
+
+@pytest.mark.parametrize("impl,dtype", IMPLS)
+@pytest.mark.parametrize("M,N,Kd", [(256, 256, 128), (300, 136, 72), (512, 768, 3072)])
+def test_gemm_nn(dev, impl, dtype, M, N, Kd):
+    A = rnd((M, Kd), dtype, dev, 1)
+    B = rnd((Kd, N), dtype, dev, 2)  # stored [K][N]
+    C = torch.empty(M, N, dtype=dtype, device=dev)
+    K.gemm(A, B, C, M, N, Kd, Kd, N, N, b_kmajor=1, impl=impl)
+    assert_close(C, A.cpu().double() @ B.cpu().double(), dtype, "NN")
+
+
+@pytest.mark.parametrize("impl,dtype", IMPLS)
+@pytest.mark.parametrize("M,N,Kd,split", [(256, 256, 128, 1), (136, 264, 200, 1), (768, 768, 4096, 4), (64, 576, 1000, 3)])
+def test_gemm_tn_f32out(dev, impl, dtype, M, N, Kd, split):
+    A = rnd((Kd, M), dtype, dev, 1)  # stored [K][M]
+    B = rnd((Kd, N), dtype, dev, 2)  # stored [K][N]
+    C0 = rnd((M, N), torch.float32, dev, 3)
+    C = C0.clone()
+    K.gemm(A, B, C, M, N, Kd, M, N, N, a_kmajor=1, b_kmajor=1, out_f32=1, accumulate=1, split_k=split, impl=impl)
+    ref = C0.cpu().double() + A.cpu().double().T @ B.cpu().double()
+    assert_close(C, ref, torch.float32, "TN accumulate", k=Kd)
+
+
+@pytest.mark.parametrize("impl,dtype", IMPLS)
+def test_gemm_tn_kcontig_b(dev, impl, dtype):
+    M, N, Kd = 128, 256, 192
+    A = rnd((Kd, M), dtype, dev, 1)
+    B = rnd((N, Kd), dtype, dev, 2)
+    C = torch.empty(M, N, dtype=dtype, device=dev)
+    K.gemm(A, B, C, M, N, Kd, M, Kd, N, a_kmajor=1, b_kmajor=0, impl=impl)
+    assert_close(C, A.cpu().double().T @ B.cpu().double().T, dtype, "TN/kc")
+
+
+@pytest.mark.parametrize("impl,dtype", IMPLS)
+def test_gemm_epilogue(dev, impl, dtype):
+    M, N, Kd = 200, 192, 128
+    A = rnd((M, Kd), dtype, dev, 1, 0.3)
+    B = rnd((N, Kd), dtype, dev, 2, 0.3)
+    bias = rnd((N,), torch.float32, dev, 3)
+    add = rnd((M, N), dtype, dev, 4)
+    pre = rnd((M, N), dtype, dev, 5)
+    acc = A.cpu().double() @ B.cpu().double().T + bias.cpu().double()
+    # bias + GELU with pre-activation side output
+    C = torch.empty(M, N, dtype=dtype, device=dev)
+    C2 = torch.empty(M, N, dtype=dtype, device=dev)
+    K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, bias=bias, C2=C2, ldc2=N, act=ACT_GELU, impl=impl)
+    assert_close(C2, acc, dtype, "pre-activation")
+    assert_close(C, F.gelu(acc), dtype, "gelu")
+    # bias + residual
+    K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, bias=bias, add=add, ldadd=N, impl=impl)
+    assert_close(C, acc + add.cpu().double(), dtype, "bias+residual")
+    # gelu' multiply (FFN backward) + add
+    x = pre.cpu().double()
+    gp = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, mul=pre, ldmul=N, add=add, ldadd=N, impl=impl)
+    assert_close(C, (A.cpu().double() @ B.cpu().double().T) * gp + add.cpu().double(), dtype, "gelu-grad")
+    # tanh / relu, fp32 output
+    Cf = torch.empty(M, N, dtype=torch.float32, device=dev)
+    K.gemm(A, B, Cf, M, N, Kd, Kd, Kd, N, bias=bias, act=ACT_TANH, out_f32=1, impl=impl)
+    assert_close(Cf, torch.tanh(acc), torch.float32 if dtype == torch.float32 else torch.bfloat16, "tanh f32")
+    K.gemm(A, B, Cf, M, N, Kd, Kd, Kd, N, bias=bias, act=ACT_RELU, out_f32=1, impl=impl)
+    assert_close(Cf, torch.relu(acc), torch.float32 if dtype == torch.float32 else torch.bfloat16, "relu f32")
+
+
+def test_gemm_f32_n3(dev):
+    M, N, Kd = 16, 3, 128
+    A = rnd((M, Kd), torch.float32, dev, 1)
+    B = rnd((N, Kd), torch.float32, dev, 2)
+    bias = rnd((N,), torch.float32, dev, 3)
+    C = torch.empty(M, N, dtype=torch.float32, device=dev)
+    K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, bias=bias, impl=GEMM_F32_SIMT)
+    assert_close(C, A.cpu().double() @ B.cpu().double().T + bias.cpu().double(), torch.float32, "N=3")
+
+
+CONVS = [  # B, H, W, Cin, Cout, k, stride, pad
+    (2, 8, 8, 64, 64, 3, 1, 1),
+    (2, 9, 7, 64, 128, 3, 2, 1),
+    (3, 8, 8, 128, 64, 1, 1, 0),
+    (2, 8, 8, 64, 128, 1, 2, 0),
+    (2, 14, 14, 128, 128, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("impl,dtype", IMPLS)
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_implicit_gemm(dev, impl, dtype, cfg):
+    B, H, W, Cin, Cout, k, s, p = cfg
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = rnd((B, H, W, Cin), dtype, dev, 1)
+    w = rnd((Cout, k, k, Cin), dtype, dev, 2, 0.1)
+    dy = rnd((B, OH, OW, Cout), dtype, dev, 3)
+    xr = x.cpu().double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.cpu().double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.conv2d(xr, wr, stride=s, padding=p)
+    yr.backward(dy.cpu().double().permute(0, 3, 1, 2))
+    Kd = k * k * Cin
+    # forward
+    y = torch.empty(B * OH * OW, Cout, dtype=dtype, device=dev)
+    g = K.conv_geom(H, W, OH, OW, k, k, s, 1, -p, 1, Cin, Cin)
+    K.gemm(x, w, y, B * OH * OW, Cout, Kd, Cin, Kd, Cout, gather=1, geom=g, impl=impl)
+    assert_close(y.view(B, OH, OW, Cout), yr.detach().permute(0, 2, 3, 1), dtype, "conv fwd")
+    # data gradient
+    dx = torch.empty(B * H * W, Cin, dtype=dtype, device=dev)
+    g = K.conv_geom(OH, OW, H, W, k, k, 1, -1, p, s, Cout, Cout)
+    K.gemm(dy, w, dx, B * H * W, Cin, k * k * Cout, Cout, Kd, Cin, b_kmajor=1, gather=1, geom=g, b_tap_stride=Cin,
+           impl=impl)
+    assert_close(dx.view(B, H, W, Cin), xr.grad.permute(0, 2, 3, 1), dtype, "conv dgrad")
+    # weight gradient (fp32 out, split-K)
+    dw = torch.zeros(Cout, Kd, dtype=torch.float32, device=dev)
+    g = K.conv_geom(H, W, OH, OW, k, k, s, 1, -p, 1, Cin, Cin)
+    K.gemm(dy, x, dw, Cout, Kd, B * OH * OW, Cout, Cin, Kd, a_kmajor=1, b_kmajor=1, gather=2, geom=g, out_f32=1,
+           split_k=2, impl=impl)
+    assert_close(dw.view(Cout, k, k, Cin), wr.grad.permute(0, 2, 3, 1), torch.float32, "conv wgrad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,H", [(64, 256), (515, 768), (33, 1024), (8, 2048)])
+def test_layernorm(dev, dtype, M, H):
+    x = rnd((M, H), dtype, dev, 1, 2.0)
+    gamma = rnd((H,), torch.float32, dev, 2)
+    beta = rnd((H,), torch.float32, dev, 3)
+    dy = rnd((M, H), dtype, dev, 4)
+    xr = x.cpu().double().requires_grad_(True)
+    gr = gamma.cpu().double().requires_grad_(True)
+    br = beta.cpu().double().requires_grad_(True)
+    yr = F.layer_norm(xr, (H,), gr, br, 1e-12)
+    yr.backward(dy.cpu().double())
+    y, mean, rstd = K.layernorm_fwd(x, gamma, beta, 1e-12)
+    assert_close(y, yr.detach(), dtype, "ln fwd")
+    dx, dg, db = K.layernorm_bwd(dy, x, mean, rstd, gamma)
+    assert_close(dx, xr.grad, dtype, "ln dx")
+    assert_close(dg, gr.grad, torch.float32, "ln dgamma")
+    assert_close(db, br.grad, torch.float32, "ln dbeta")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum(dev, dtype):
+    x = rnd((1000, 2304), dtype, dev, 1)
+    out = rnd((2304,), torch.float32, dev, 2)
+    ref = out.cpu().double() + x.cpu().double().sum(0)
+    K.colsum(x, out, accumulate=1)
+    assert_close(out, ref, torch.float32, "colsum")
+
+
+def attn_ref(qkv, mask, dctx, B, S, heads):
+    Hd = heads * 64
+    t = qkv.cpu().double().view(B, S, 3, heads, 64).requires_grad_(True)
+    q, k, v = t[:, :, 0].transpose(1, 2), t[:, :, 1].transpose(1, 2), t[:, :, 2].transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / 8.0
+    if mask is not None:
+        s = s.masked_fill(mask.cpu()[:, None, None, :] == 0, -1e30)
+    p = torch.softmax(s, -1)
+    ctx = (p @ v).transpose(1, 2).reshape(B * S, Hd)
+    ctx.backward(dctx.cpu().double())
+    return ctx.detach(), t.grad.reshape(B * S, 3 * Hd)
+
+
+@pytest.mark.parametrize("impl,dtype", IMPLS)
+@pytest.mark.parametrize("B,S,heads,masked", [(2, 128, 2, False), (3, 32, 4, True), (2, 64, 1, True), (1, 16, 2, False),
+                                              (2, 48, 2, True), (1, 256, 1, False)])
+def test_attention(dev, impl, dtype, B, S, heads, masked):
+    Hd = heads * 64
+    qkv = rnd((B * S, 3 * Hd), dtype, dev, 1)
+    dctx = rnd((B * S, Hd), dtype, dev, 2)
+    mask = None
+    if masked:
+        mask = torch.ones(B, S)
+        for b in range(B):
+            mask[b, S - 3 - 2 * b:] = 0
+        mask = mask.to(dev)
+    ctx_ref, dqkv_ref = attn_ref(qkv, mask, dctx, B, S, heads)
+    ctx = K.attention_fwd(qkv, mask, B, S, heads, impl=impl)
+    tol_dtype = dtype
+    assert_close(ctx, ctx_ref, tol_dtype, "attn fwd")
+    dqkv = K.attention_bwd(qkv, mask, dctx, B, S, heads, impl=impl)
+    got = dqkv.cpu().double()
+    scale = dqkv_ref.abs().max().item()
+    err = (got - dqkv_ref).abs().max().item() / scale
+    assert err < (3e-2 if dtype == torch.bfloat16 else 1e-4), f"attn bwd err {err}"
