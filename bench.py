@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one training step (forward + CE + backward + gradient all-reduce + clip + AdamW) of
+BERT-base + ResNet-50 + the reference's attention fusion head on synthetic 224x224 RGB + 128-token batches, bs=64/GPU.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (BASELINE.json metric: (image,text) pairs/sec/node). `roofline` is measured live: every
+bf16 MFMA GEMM launch of the timed region is bracketed by HIP events on its launch stream (mmsa_prof_*); `cpu_baseline`
+is the CPU oracle's train step (oracle/model.py) timed on the host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FWD_GFLOP_PER_PAIR = 30.52  # BERT-base S=128 22.348 + ResNet-50 (no fc) 8.174, 2 FLOP/MAC
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def synth_batch(B, S, vocab, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(B, 3, 224, 224, generator=g)
+    ids = torch.randint(0, vocab, (B, S), generator=g)
+    ids[:, 0] = 101
+    mask = torch.ones(B, S)
+    labels = torch.randint(0, 3, (B,), generator=g)
+    return image.to(device), ids.to(device), mask.to(device), labels.to(device)
+
+
+def cpu_baseline(model, B, steps):
+    """Reference-style train step of the CPU oracle (fp32) on the host cores: the reported baseline, not the product."""
+    from oracle import model as OM
+    from oracle.bert import BERT_BASE as OB
+    from oracle.resnet import RESNET50 as OR
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
+    names = [n for n, _ in model.named_parameters() if n not in ("contrastive_weight", "temperature")]
+    cfg = dict(bert=OB, resnet=OR)
+    image, ids, mask, labels = synth_batch(B, 128, 30522, "cpu", 1234)
+    opt = {}
+    OM.train_step(sd, names, image, ids, mask, labels, cfg, opt)  # warm-up (allocations, oneDNN primitives)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        OM.train_step(sd, names, image, ids, mask, labels, cfg, opt)
+    dt = time.perf_counter() - t0
+    return {"value": round(B * steps / dt, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} fp32 train steps (fwd+CE+bwd+clip+AdamW) of the CPU oracle at B={B}, S=128, 224x224 after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-baseline-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import multimodal_sentiment_aanalysis_amd as mm
+    from multimodal_sentiment_aanalysis_amd import _lib
+    from multimodal_sentiment_aanalysis_amd.fused import FusedTrainStep
+
+    torch.manual_seed(0)
+    model = mm.MultimodalTransformerModel()  # BERT-base + ResNet-50 + fusion head, random init (no checkpoints offline)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(model, 16, args.cpu_baseline_steps)
+    trainer = FusedTrainStep(model, device, precision=args.precision)
+    batch = synth_batch(args.batch, args.seq, 30522, device, 1234 + rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(*batch)
+    L = _lib.load()
+    sync()
+    L.mmsa_prof_begin(args.steps * 1200)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.step(*batch)
+    sync()
+    dt = time.perf_counter() - t0
+    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    L.mmsa_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+    el = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    dt = el.item()
+    if rank == 0:
+        pairs = args.batch * world * args.steps
+        gemm_tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        step_tflops = pairs * 3 * FWD_GFLOP_PER_PAIR / dt / 1e3 / world
+        out = {
+            "metric": "(image,text) pairs/sec/node, BERT-base+ResNet50 bs=64/GPU",
+            "value": round(pairs / dt, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "train step (fwd+CE+bwd+grad all-reduce+clip+AdamW): BERT-base S=%d + ResNet-50 224x224 + "
+                                   "MHA fusion head, 3-class CE, random init" % args.seq,
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": args.seq,
+                       "image": "224x224x3", "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_bf16_kernel (all NT/NN/TN/implicit-conv launches of the timed steps)",
+                         "launches": n.value, "kernel_ms_per_step": round(ms.value / args.steps, 3),
+                         "step_algorithmic_tflops_per_gpu": round(step_tflops, 2),
+                         "step_frac_of_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4)},
+            "loss": round(float(loss), 5),
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

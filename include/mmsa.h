@@ -115,6 +115,119 @@ int mmsa_attention_fwd(int32_t impl, const void* qkv, const float* mask, void* c
 int mmsa_attention_bwd(int32_t impl, const void* qkv, const float* mask, const void* dctx, void* dqkv, float* ws,
                        int32_t B, int32_t S, int32_t heads, int32_t head_dim, void* stream);
 
+/* ---- BERT text encoder engine (fills the encoder slot MultimodalModel.py:264-266; NOT in the reference) ------
+ * Parameters live in ONE flat fp32 buffer (`w32`) whose layout is reported by mmsa_bert_param_info (HF BertModel
+ * names under "bert.", plus "proj.*" = Linear(hidden, out_dim) into the fusion width). `wt` is the working copy in
+ * the storage dtype with the same element offsets (== w32 for fp32). Gradients go to a flat fp32 buffer with
+ * the same offsets (+= when accumulate, = otherwise). `ws` (mmsa_bert_ws_bytes) holds the activations saved by
+ * the forward for the backward, which must see the same ws, ids and mask. */
+typedef struct mmsa_bert_cfg {
+  int32_t batch, seq, hidden, layers, heads, intermediate, vocab, max_pos, type_vocab, out_dim, dtype;
+  float ln_eps;
+} mmsa_bert_cfg;
+int mmsa_bert_param_count(const mmsa_bert_cfg* c);
+int64_t mmsa_bert_param_total(const mmsa_bert_cfg* c);
+int mmsa_bert_param_info(const mmsa_bert_cfg* c, int idx, char* name, int name_cap, int64_t* offset, int32_t* ndim,
+                         int64_t* shape /*[4]*/);
+size_t mmsa_bert_ws_bytes(const mmsa_bert_cfg* c);
+int mmsa_bert_fwd(const mmsa_bert_cfg* c, const float* w32, const void* wt, const int64_t* ids, const float* mask, void* ws,
+                  float* feat /*[batch][out_dim] fp32*/, void* stream);
+int mmsa_bert_bwd(const mmsa_bert_cfg* c, const float* w32, const void* wt, const int64_t* ids, const float* mask, void* ws,
+                  const float* dfeat, float* grad, int32_t accumulate, void* stream);
+
+/* ---- ResNet (bottleneck v1.5) image encoder engine (encoder slot; NOT in the reference) -------------------------
+ * image is NCHW fp32 [batch][3][height][width] as the reference-style loaders deliver it; everything inside is NHWC
+ * in the storage dtype. Convolution weights are physically [Cout][KH][KW][Cin] (channels_last of the logical
+ * torchvision shape). `bnbuf` = flat fp32 running_mean / running_var buffers (param_info with buffers = 1),
+ * updated in training mode. */
+typedef struct mmsa_resnet_cfg {
+  int32_t batch, height, width;
+  int32_t blocks[4], widths[4];
+  int32_t out_dim, dtype, training;
+  float bn_eps, bn_momentum;
+} mmsa_resnet_cfg;
+int mmsa_resnet_param_count(const mmsa_resnet_cfg* c, int32_t buffers);
+int64_t mmsa_resnet_param_total(const mmsa_resnet_cfg* c, int32_t buffers);
+int mmsa_resnet_param_info(const mmsa_resnet_cfg* c, int32_t buffers, int idx, char* name, int name_cap, int64_t* offset,
+                           int32_t* ndim, int64_t* shape /*[4]*/);
+size_t mmsa_resnet_ws_bytes(const mmsa_resnet_cfg* c);
+int mmsa_resnet_fwd(const mmsa_resnet_cfg* c, const float* w32, const void* wt, float* bnbuf, const float* image, void* ws,
+                    float* feat /*[batch][out_dim] fp32*/, void* stream);
+int mmsa_resnet_bwd(const mmsa_resnet_cfg* c, const float* w32, const void* wt, void* ws, const float* dfeat, float* grad,
+                    int32_t accumulate, void* stream);
+
+/* ---- fusion-head engines (fp32) ---------------------------------------------------------------------------------
+ * kind 0 CrossModalTransformer (MultimodalModel.py:108-149): inputs {query[B,E], key[B,Lk,E], value[B,Lk,E]} -> {out[B,E]}
+ * kind 1 ME-MHACL fusion       (MultimodalModel.py:374-404): inputs {feat_0..feat_{tokens-1} [B,E]} -> {fused[B,E]}
+ * kind 2 weighted head         (MultimodalModel.py:171-225,298-313): inputs {anchor, raw2, raw3, enh2, enh3 [B,E]}
+ *                              -> {logits[B,C], fused[B,128], valence logits[B,C] if cfg.valence}
+ * kind 3 Classifier            (MultimodalModel.py:432-451): {x[B,E]} -> {out_a[B,C], out_v[B,C]}
+ * kind 4 ProjectionHead        (MultimodalModel.py:409-429): {x[B,E]} -> {z[B,out_dim]}
+ * Parameter names reported by mmsa_head_param_info are the reference's state_dict keys. Backward takes the same
+ * inputs and ws as the forward, douts in output order (a NULL dout means zero), writes dinputs in input order (a NULL
+ * dinput is skipped where the module allows) and parameter gradients into `grad` (NULL = parameters frozen). */
+#define MMSA_HEAD_CROSS_MODAL 0
+#define MMSA_HEAD_MM_FUSION 1
+#define MMSA_HEAD_WEIGHTED 2
+#define MMSA_HEAD_CLASSIFIER 3
+#define MMSA_HEAD_PROJECTION 4
+typedef struct mmsa_head_cfg {
+  int32_t batch, embed, tokens, heads, pool_mode /*0 max, 1 mean*/, num_classes, valence, hidden, out_dim, training;
+  float bn_eps, bn_momentum, ln_eps, dropout_p;
+  uint64_t seed; /* dropout stream for this call (the backward must see the same value) */
+} mmsa_head_cfg;
+int mmsa_head_param_count(int32_t kind, const mmsa_head_cfg* c, int32_t buffers);
+int64_t mmsa_head_param_total(int32_t kind, const mmsa_head_cfg* c, int32_t buffers);
+int mmsa_head_param_info(int32_t kind, const mmsa_head_cfg* c, int32_t buffers, int idx, char* name, int name_cap,
+                         int64_t* offset, int32_t* ndim, int64_t* shape /*[4]*/);
+size_t mmsa_head_ws_bytes(int32_t kind, const mmsa_head_cfg* c);
+int mmsa_head_fwd(int32_t kind, const mmsa_head_cfg* c, const float* w, float* bnbuf, const float* const* inputs,
+                  float* const* outputs, void* ws, void* stream);
+int mmsa_head_bwd(int32_t kind, const mmsa_head_cfg* c, const float* w, const float* const* inputs, const float* const* douts,
+                  float* const* dinputs, float* grad, int32_t accumulate, void* ws, void* stream);
+
+/* ---- fused cross-entropy forward + backward entry: nn.CrossEntropyLoss() at Trainer.py:17,68; Tester.py:20,57 ----
+ * loss = mean_b -log softmax(logits)[b, labels[b]]; dlogits = grad_scale * (softmax - onehot) / B (NULL to skip);
+ * probs = softmax (NULL to skip; Tester.py:54). */
+int mmsa_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits, float* probs, int32_t B,
+                    int32_t C, float grad_scale, void* stream);
+
+/* ---- step tail over flat buffers: clip_grad_norm_(1.0) + AdamW (Trainer.py:19-21,80-81) ---------------------------
+ * mmsa_grad_norm: norm_out[0] = grad_scale * ||g||_2, norm_out[1] = min(1, max_norm / (norm + 1e-6)) (device memory).
+ * mmsa_adamw_step: decoupled-decay AdamW on w using g * norm_clip[1] * grad_scale; also refreshes the bf16 working
+ * copy w16 (may be NULL). grad_scale carries the 1/world_size of the data-parallel gradient average. */
+size_t mmsa_grad_norm_ws_bytes(void);
+int mmsa_grad_norm(const float* g, int64_t n, float grad_scale, float max_norm, float* norm_out, void* ws, void* stream);
+int mmsa_adamw_step(float* w, const float* g, float* m, float* v, void* w16, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int32_t step, const float* norm_clip, float grad_scale, void* stream);
+/* storage cast fp32 -> dtype (refresh of the working weights after a foreign optimizer touched the fp32 master) */
+int mmsa_cast_f32(int32_t dtype, const float* src, void* dst, int64_t n, void* stream);
+
+/* ---- BatchNorm over the rows of [M][C] (nn.BatchNorm1d: MultimodalModel.py:181,186,194,380; BatchNorm2d of the
+ * ResNet encoder on NHWC), fused affine (+ residual) + activation; two-stage deterministic statistics ----------- */
+size_t mmsa_bn_ws_bytes(int32_t C);
+int mmsa_bn_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                float* mean, float* invstd, const void* res, void* y, float* ws, int32_t M, int32_t C, float eps,
+                float momentum, int32_t act, int32_t training, void* stream);
+int mmsa_bn_bwd(int32_t dtype, const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
+                const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, int32_t accumulate,
+                float* ws, int32_t M, int32_t C, int32_t act, int32_t training, void* stream);
+/* ---- pooling / stem layout kernels of the ResNet encoder (NHWC) ---------------------------------------------------- */
+int mmsa_maxpool_fwd(int32_t dtype, const void* x, void* y, uint8_t* idx, int32_t B, int32_t H, int32_t W, int32_t C,
+                     void* stream);
+int mmsa_maxpool_bwd(int32_t dtype, const void* dy, const uint8_t* idx, void* dx, int32_t B, int32_t H, int32_t W, int32_t C,
+                     void* stream);
+int mmsa_avgpool_fwd(int32_t dtype, const void* x, void* y, int32_t B, int32_t HW, int32_t C, void* stream);
+int mmsa_avgpool_bwd(int32_t dtype, const void* dy, void* dx, int32_t B, int32_t HW, int32_t C, void* stream);
+int mmsa_stem_im2col(int32_t dtype, const float* img, void* col, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t OH,
+                     int32_t OW, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t Kpad, void* stream);
+
+/* ---- live timing of the MFMA GEMM launches (bench.py `roofline`): when enabled, every bf16 MFMA GEMM launch (incl.
+ * its split-K reduction) is bracketed by HIP events on its launch stream. mmsa_prof_end must be called after the
+ * stream has been synchronized; it returns the summed device time, the algorithmic flop (2*M*N*K) and the count. */
+int mmsa_prof_begin(int32_t max_records);
+int mmsa_prof_end(double* total_ms, double* total_flop, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,29 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class BertCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("batch", "seq", "hidden", "layers", "heads", "intermediate", "vocab", "max_pos", "type_vocab",
+                 "out_dim", "dtype")] + [("ln_eps", ctypes.c_float)]
+
+
+class ResnetCfg(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32),
+                ("blocks", ctypes.c_int32 * 4), ("widths", ctypes.c_int32 * 4),
+                ("out_dim", ctypes.c_int32), ("dtype", ctypes.c_int32), ("training", ctypes.c_int32),
+                ("bn_eps", ctypes.c_float), ("bn_momentum", ctypes.c_float)]
+
+
+class HeadCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("batch", "embed", "tokens", "heads", "pool_mode", "num_classes", "valence", "hidden", "out_dim",
+                 "training")] + [("bn_eps", ctypes.c_float), ("bn_momentum", ctypes.c_float),
+                                 ("ln_eps", ctypes.c_float), ("dropout_p", ctypes.c_float),
+                                 ("seed", ctypes.c_uint64)]
+
+
+HEAD_CROSS_MODAL, HEAD_MM_FUSION, HEAD_WEIGHTED, HEAD_CLASSIFIER, HEAD_PROJECTION = 0, 1, 2, 3, 4
+
 _lib = None
 
 
@@ -60,8 +83,6 @@ def load():
             "(or __graft_entry__.build()). There is no CPU fallback for the product path.")
     _lib = ctypes.CDLL(LIB_PATH)
     _lib.mmsa_abi_version.restype = ctypes.c_int
-    for name in dir(_lib):
-        pass
     _declare(_lib)
     return _lib
 
@@ -81,6 +102,43 @@ def _declare(L):
         "mmsa_attention_fwd": (ctypes.c_int, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
         "mmsa_attention_bwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     }
+    P = ctypes.POINTER
+    i64p, i32p, pp = P(ctypes.c_int64), P(ctypes.c_int32), P(ctypes.c_void_p)
+    sig.update({
+        "mmsa_bert_param_count": (ctypes.c_int, [P(BertCfg)]),
+        "mmsa_bert_param_total": (i64, [P(BertCfg)]),
+        "mmsa_bert_param_info": (ctypes.c_int, [P(BertCfg), ctypes.c_int, ctypes.c_char_p, ctypes.c_int, i64p, i32p, i64p]),
+        "mmsa_bert_ws_bytes": (sz, [P(BertCfg)]),
+        "mmsa_bert_fwd": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp]),
+        "mmsa_bert_bwd": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+        "mmsa_resnet_param_count": (ctypes.c_int, [P(ResnetCfg), i32]),
+        "mmsa_resnet_param_total": (i64, [P(ResnetCfg), i32]),
+        "mmsa_resnet_param_info": (ctypes.c_int, [P(ResnetCfg), i32, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, i64p, i32p, i64p]),
+        "mmsa_resnet_ws_bytes": (sz, [P(ResnetCfg)]),
+        "mmsa_resnet_fwd": (ctypes.c_int, [P(ResnetCfg), vp, vp, vp, vp, vp, vp, vp]),
+        "mmsa_resnet_bwd": (ctypes.c_int, [P(ResnetCfg), vp, vp, vp, vp, vp, i32, vp]),
+        "mmsa_head_param_count": (ctypes.c_int, [i32, P(HeadCfg), i32]),
+        "mmsa_head_param_total": (i64, [i32, P(HeadCfg), i32]),
+        "mmsa_head_param_info": (ctypes.c_int, [i32, P(HeadCfg), i32, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, i64p, i32p, i64p]),
+        "mmsa_head_ws_bytes": (sz, [i32, P(HeadCfg)]),
+        "mmsa_head_fwd": (ctypes.c_int, [i32, P(HeadCfg), vp, vp, pp, pp, vp, vp]),
+        "mmsa_head_bwd": (ctypes.c_int, [i32, P(HeadCfg), vp, pp, pp, pp, vp, i32, vp, vp]),
+        "mmsa_ce_fwd_bwd": (ctypes.c_int, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+        "mmsa_grad_norm_ws_bytes": (sz, []),
+        "mmsa_grad_norm": (ctypes.c_int, [vp, i64, f32, f32, vp, vp, vp]),
+        "mmsa_adamw_step": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp]),
+        "mmsa_cast_f32": (ctypes.c_int, [i32, vp, vp, i64, vp]),
+        "mmsa_prof_begin": (ctypes.c_int, [i32]),
+        "mmsa_prof_end": (ctypes.c_int, [P(ctypes.c_double), P(ctypes.c_double), i64p]),
+        "mmsa_bn_ws_bytes": (sz, [i32]),
+        "mmsa_bn_fwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, i32, vp]),
+        "mmsa_bn_bwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]),
+        "mmsa_maxpool_fwd": (ctypes.c_int, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+        "mmsa_maxpool_bwd": (ctypes.c_int, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+        "mmsa_avgpool_fwd": (ctypes.c_int, [i32, vp, vp, i32, i32, i32, vp]),
+        "mmsa_avgpool_bwd": (ctypes.c_int, [i32, vp, vp, i32, i32, i32, vp]),
+        "mmsa_stem_im2col": (ctypes.c_int, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    })
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype = res
@@ -106,3 +164,26 @@ def dtype_code(t):
     if t.dtype == torch.bfloat16:
         return MMSA_BF16
     raise MmsaError(f"unsupported storage dtype {t.dtype}")
+
+
+def ptr_array(tensors):
+    """void*[] of device pointers (None -> NULL)."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def param_table(count_fn, info_fn):
+    """Read a parameter layout table from the library: [(name, offset, shape tuple)]."""
+    out = []
+    name = ctypes.create_string_buffer(256)
+    off, nd = ctypes.c_int64(), ctypes.c_int32()
+    shape = (ctypes.c_int64 * 4)()
+    n = count_fn()
+    if n < 0:
+        raise MmsaError("invalid engine configuration")
+    for i in range(n):
+        check(info_fn(i, name, 256, ctypes.byref(off), ctypes.byref(nd), shape), "param_info")
+        out.append((name.value.decode(), off.value, tuple(shape[j] for j in range(nd.value))))
+    return out

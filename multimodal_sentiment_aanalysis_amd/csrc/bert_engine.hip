@@ -1,0 +1,262 @@
+// BERT text encoder engine: one call runs the whole forward (embeddings -> L post-LN layers -> tanh pooler ->
+// Linear(H, D) projection into the fusion width) and one call the whole backward, as a fixed sequence of kernel
+// launches on the caller's stream over a caller-provided workspace (no allocation, no sync: hipGraph-capturable).
+//
+// NOT IN THE REFERENCE: BERT fills the reference's encoder slot (MultimodalModel.py:264-266); the arithmetic is the
+// public BERT architecture (HF BertModel names are kept for the parameters). Storage dtype bf16 -> MFMA GEMMs and
+// MFMA attention; fp32 -> SIMT kernels (exact mode).
+//
+// Flat parameter layout (elements; same offsets in the fp32 master, the storage-type working copy and the fp32
+// gradient buffer): query/key/value weights (and biases) of a layer are adjacent so the QKV projection is ONE GEMM.
+#include "../../include/mmsa.h"
+#include "engine_common.h"
+
+struct BertLayerOff {
+  long wqkv, bqkv, wo, bo, ln1w, ln1b, w1, b1, w2, b2, ln2w, ln2b;
+};
+struct BertLayout {
+  ParamTable t;
+  long word, pos, type, lnw, lnb, wp, bp, wproj, bproj;
+  std::vector<BertLayerOff> L;
+};
+
+static BertLayout bert_layout(const mmsa_bert_cfg& c) {
+  BertLayout o;
+  ParamTable& t = o.t;
+  const long H = c.hidden, I = c.intermediate;
+  o.word = t.add("bert.embeddings.word_embeddings.weight", {c.vocab, H});
+  o.pos = t.add("bert.embeddings.position_embeddings.weight", {c.max_pos, H});
+  o.type = t.add("bert.embeddings.token_type_embeddings.weight", {c.type_vocab, H});
+  o.lnw = t.add("bert.embeddings.LayerNorm.weight", {H});
+  o.lnb = t.add("bert.embeddings.LayerNorm.bias", {H});
+  for (int l = 0; l < c.layers; ++l) {
+    const std::string p = "bert.encoder.layer." + std::to_string(l) + ".";
+    BertLayerOff f;
+    // H*H and H are multiples of 64 for every supported config, so q|k|v stay contiguous
+    f.wqkv = t.add(p + "attention.self.query.weight", {H, H});
+    t.add(p + "attention.self.key.weight", {H, H});
+    t.add(p + "attention.self.value.weight", {H, H});
+    f.bqkv = t.add(p + "attention.self.query.bias", {H});
+    t.add(p + "attention.self.key.bias", {H});
+    t.add(p + "attention.self.value.bias", {H});
+    f.wo = t.add(p + "attention.output.dense.weight", {H, H});
+    f.bo = t.add(p + "attention.output.dense.bias", {H});
+    f.ln1w = t.add(p + "attention.output.LayerNorm.weight", {H});
+    f.ln1b = t.add(p + "attention.output.LayerNorm.bias", {H});
+    f.w1 = t.add(p + "intermediate.dense.weight", {I, H});
+    f.b1 = t.add(p + "intermediate.dense.bias", {I});
+    f.w2 = t.add(p + "output.dense.weight", {H, I});
+    f.b2 = t.add(p + "output.dense.bias", {H});
+    f.ln2w = t.add(p + "output.LayerNorm.weight", {H});
+    f.ln2b = t.add(p + "output.LayerNorm.bias", {H});
+    o.L.push_back(f);
+  }
+  o.wp = t.add("bert.pooler.dense.weight", {H, H});
+  o.bp = t.add("bert.pooler.dense.bias", {H});
+  o.wproj = t.add("proj.weight", {c.out_dim, H});
+  o.bproj = t.add("proj.bias", {c.out_dim});
+  return o;
+}
+
+static bool bert_cfg_ok(const mmsa_bert_cfg& c) {
+  return c.batch > 0 && c.seq > 0 && c.seq <= c.max_pos && c.hidden % 64 == 0 && c.heads > 0 &&
+         c.hidden == c.heads * 64 && c.intermediate % 64 == 0 && c.out_dim % 64 == 0 && c.layers > 0 &&
+         c.vocab > 0 && c.type_vocab > 0 && (c.dtype == MMSA_F32 || c.dtype == MMSA_BF16);
+}
+
+struct BertLayerWs {
+  void *qkv, *ctx, *s1, *h1, *pre, *act, *s2, *out;
+  float *mean1, *rstd1, *mean2, *rstd2;
+};
+struct BertWs {
+  void *e, *x0;
+  float *mean0, *rstd0;
+  std::vector<BertLayerWs> L;
+  void *pooled, *dfeat_t, *dpool, *dprepool;
+  void *bufA, *bufB, *bufC, *bufI, *bufQ;
+  float *splitk, *colws, *lnws, *attnws;
+  size_t splitk_bytes;
+  size_t total;
+};
+
+static BertWs bert_ws(const mmsa_bert_cfg& c, void* base) {
+  BertWs w;
+  Bump b(base);
+  const size_t es = c.dtype == MMSA_BF16 ? 2 : 4;
+  const size_t M = (size_t)c.batch * c.seq, H = c.hidden, I = c.intermediate;
+  w.e = b.take(M * H * es);
+  w.x0 = b.take(M * H * es);
+  w.mean0 = (float*)b.take(M * 4);
+  w.rstd0 = (float*)b.take(M * 4);
+  for (int l = 0; l < c.layers; ++l) {
+    BertLayerWs x;
+    x.qkv = b.take(M * 3 * H * es);
+    x.ctx = b.take(M * H * es);
+    x.s1 = b.take(M * H * es);
+    x.h1 = b.take(M * H * es);
+    x.pre = b.take(M * I * es);
+    x.act = b.take(M * I * es);
+    x.s2 = b.take(M * H * es);
+    x.out = b.take(M * H * es);
+    x.mean1 = (float*)b.take(M * 4);
+    x.rstd1 = (float*)b.take(M * 4);
+    x.mean2 = (float*)b.take(M * 4);
+    x.rstd2 = (float*)b.take(M * 4);
+    w.L.push_back(x);
+  }
+  w.pooled = b.take((size_t)c.batch * H * es);
+  w.dfeat_t = b.take((size_t)c.batch * c.out_dim * es);
+  w.dpool = b.take((size_t)c.batch * H * es);
+  w.dprepool = b.take((size_t)c.batch * H * es);
+  w.bufA = b.take(M * H * es);
+  w.bufB = b.take(M * H * es);
+  w.bufC = b.take(M * H * es);
+  w.bufI = b.take(M * I * es);
+  w.bufQ = b.take(M * 3 * H * es);
+  // split-K slabs: the largest weight gradient is [I][H]; allow up to 8 slabs of it (pick_split respects the size)
+  w.splitk_bytes = (size_t)8 * I * H * sizeof(float);
+  w.splitk = (float*)b.take(w.splitk_bytes);
+  size_t colb = colsum_ws_bytes((int)(3 * H > I ? 3 * H : I));
+  w.colws = (float*)b.take(colb);
+  w.lnws = (float*)b.take(layernorm_bwd_ws_bytes((int)H));
+  w.attnws = (float*)b.take(attention_bwd_ws_bytes(c.batch, c.seq, c.heads));
+  w.total = b.off;
+  return w;
+}
+
+static inline const char* at(const void* base, long off, size_t es) { return (const char*)base + (size_t)off * es; }
+
+extern "C" {
+
+int mmsa_bert_param_count(const mmsa_bert_cfg* c) {
+  if (!c || !bert_cfg_ok(*c)) return -1;
+  return (int)bert_layout(*c).t.entries.size();
+}
+int64_t mmsa_bert_param_total(const mmsa_bert_cfg* c) {
+  if (!c || !bert_cfg_ok(*c)) return -1;
+  return bert_layout(*c).t.total;
+}
+int mmsa_bert_param_info(const mmsa_bert_cfg* c, int idx, char* name, int name_cap, int64_t* offset, int32_t* ndim,
+                         int64_t* shape) {
+  if (!c || !bert_cfg_ok(*c)) return MMSA_ERR_ARG;
+  const BertLayout L = bert_layout(*c);
+  if (idx < 0 || idx >= (int)L.t.entries.size()) return MMSA_ERR_ARG;
+  const ParamEntry& e = L.t.entries[idx];
+  if ((int)e.name.size() + 1 > name_cap) return MMSA_ERR_ARG;
+  strcpy(name, e.name.c_str());
+  *offset = e.offset;
+  *ndim = e.ndim;
+  for (int i = 0; i < 4; ++i) shape[i] = e.shape[i];
+  return MMSA_OK;
+}
+size_t mmsa_bert_ws_bytes(const mmsa_bert_cfg* c) {
+  if (!c || !bert_cfg_ok(*c)) return 0;
+  return bert_ws(*c, nullptr).total;
+}
+
+int mmsa_bert_fwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, const int64_t* ids, const float* mask,
+                  void* ws_base, float* feat, void* stream) {
+  if (!cp || !bert_cfg_ok(*cp) || !w32 || !wt || !ids || !ws_base || !feat) return MMSA_ERR_ARG;
+  const mmsa_bert_cfg& c = *cp;
+  const BertLayout lay = bert_layout(c);
+  BertWs ws = bert_ws(c, ws_base);
+  hipStream_t st = (hipStream_t)stream;
+  Eng e{c.dtype, st, ws.splitk, ws.splitk_bytes, ws.colws};
+  const size_t es = e.esz();
+  const int M = c.batch * c.seq, H = c.hidden, I = c.intermediate, S = c.seq;
+  const int aimpl = e.attn_impl();
+  auto W = [&](long off) { return (const void*)at(wt, off, es); };
+  auto P = [&](long off) { return w32 + off; };
+
+  RET_IF(embed_gather(c.dtype, (const long long*)ids, W(lay.word), W(lay.pos), W(lay.type), ws.e, M, S, H, c.vocab, st));
+  RET_IF(layernorm_fwd(c.dtype, ws.e, P(lay.lnw), P(lay.lnb), ws.x0, ws.mean0, ws.rstd0, M, H, c.ln_eps, st));
+  const void* x = ws.x0;
+  for (int l = 0; l < c.layers; ++l) {
+    const BertLayerOff& f = lay.L[l];
+    BertLayerWs& a = ws.L[l];
+    RET_IF(e.linear_fwd(x, H, W(f.wqkv), P(f.bqkv), a.qkv, 3 * H, M, 3 * H, H));
+    RET_IF(attention_fwd(aimpl, a.qkv, mask, a.ctx, c.batch, S, c.heads, 64, st));
+    RET_IF(e.linear_fwd(a.ctx, H, W(f.wo), P(f.bo), a.s1, H, M, H, H, MMSA_ACT_NONE, nullptr, x, H));
+    RET_IF(layernorm_fwd(c.dtype, a.s1, P(f.ln1w), P(f.ln1b), a.h1, a.mean1, a.rstd1, M, H, c.ln_eps, st));
+    RET_IF(e.linear_fwd(a.h1, H, W(f.w1), P(f.b1), a.act, I, M, I, H, MMSA_ACT_GELU, a.pre));
+    RET_IF(e.linear_fwd(a.act, I, W(f.w2), P(f.b2), a.s2, H, M, H, I, MMSA_ACT_NONE, nullptr, a.h1, H));
+    RET_IF(layernorm_fwd(c.dtype, a.s2, P(f.ln2w), P(f.ln2b), a.out, a.mean2, a.rstd2, M, H, c.ln_eps, st));
+    x = a.out;
+  }
+  // pooler on the first token of every sequence (row stride S*H), then the projection into the fusion width (fp32 out)
+  RET_IF(e.linear_fwd(x, (long)S * H, W(lay.wp), P(lay.bp), ws.pooled, H, c.batch, H, H, MMSA_ACT_TANH));
+  RET_IF(e.linear_fwd(ws.pooled, H, W(lay.wproj), P(lay.bproj), feat, c.out_dim, c.batch, c.out_dim, H, MMSA_ACT_NONE,
+                      nullptr, nullptr, 0, 1));
+  return MMSA_OK;
+}
+
+int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, const int64_t* ids, const float* mask,
+                  void* ws_base, const float* dfeat, float* grad, int32_t accumulate, void* stream) {
+  if (!cp || !bert_cfg_ok(*cp) || !w32 || !wt || !ids || !ws_base || !dfeat || !grad) return MMSA_ERR_ARG;
+  const mmsa_bert_cfg& c = *cp;
+  const BertLayout lay = bert_layout(c);
+  BertWs ws = bert_ws(c, ws_base);
+  hipStream_t st = (hipStream_t)stream;
+  Eng e{c.dtype, st, ws.splitk, ws.splitk_bytes, ws.colws};
+  const size_t es = e.esz();
+  const int M = c.batch * c.seq, H = c.hidden, I = c.intermediate, S = c.seq, B = c.batch, D = c.out_dim;
+  const int aimpl = e.attn_impl();
+  const int acc = accumulate ? 1 : 0;
+  auto W = [&](long off) { return (const void*)at(wt, off, es); };
+  auto P = [&](long off) { return w32 + off; };
+  auto G = [&](long off) { return grad + off; };
+
+  const void* xL = ws.L[c.layers - 1].out;
+  // projection + pooler
+  RET_IF(cast_f32(c.dtype, dfeat, ws.dfeat_t, (long)B * D, st));
+  RET_IF(e.bias_grad(ws.dfeat_t, D, G(lay.bproj), B, D, acc));
+  RET_IF(e.linear_wgrad(ws.dfeat_t, D, ws.pooled, H, G(lay.wproj), B, D, H, acc));
+  RET_IF(e.linear_dgrad(ws.dfeat_t, D, W(lay.wproj), ws.dpool, H, B, D, H));
+  RET_IF(tanh_bwd(c.dtype, ws.dpool, ws.pooled, ws.dprepool, (long)B * H, st));
+  RET_IF(e.bias_grad(ws.dprepool, H, G(lay.bp), B, H, acc));
+  RET_IF(e.linear_wgrad(ws.dprepool, H, xL, (long)S * H, G(lay.wp), B, H, H, acc));
+  void *dOut = ws.bufA, *bB = ws.bufB, *bC = ws.bufC;
+  if (hipMemsetAsync(dOut, 0, (size_t)M * H * es, st) != hipSuccess) return MMSA_ERR_LAUNCH;
+  RET_IF(e.linear_dgrad(ws.dprepool, H, W(lay.wp), dOut, (long)S * H, B, H, H));  // only the [CLS] rows receive gradient
+
+  for (int l = c.layers - 1; l >= 0; --l) {
+    const BertLayerOff& f = lay.L[l];
+    BertLayerWs& a = ws.L[l];
+    const void* xin = l == 0 ? ws.x0 : ws.L[l - 1].out;
+    void* ds2 = bB;
+    RET_IF(layernorm_bwd(c.dtype, dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, G(f.ln2w), G(f.ln2b), acc, ws.lnws, M, H, st));
+    RET_IF(e.bias_grad(ds2, H, G(f.b2), M, H, acc));
+    RET_IF(e.linear_wgrad(ds2, H, a.act, I, G(f.w2), M, H, I, acc));
+    void* dpre = ws.bufI;
+    RET_IF(e.linear_dgrad(ds2, H, W(f.w2), dpre, I, M, H, I, a.pre, I));  // * gelu'(pre)
+    RET_IF(e.bias_grad(dpre, I, G(f.b1), M, I, acc));
+    RET_IF(e.linear_wgrad(dpre, I, a.h1, H, G(f.w1), M, I, H, acc));
+    void* dh1 = bC;
+    RET_IF(e.linear_dgrad(dpre, I, W(f.w1), dh1, H, M, I, H, nullptr, 0, ds2, H));  // + residual branch
+    void* ds1 = dOut;
+    RET_IF(layernorm_bwd(c.dtype, dh1, a.s1, a.mean1, a.rstd1, P(f.ln1w), ds1, G(f.ln1w), G(f.ln1b), acc, ws.lnws, M, H, st));
+    RET_IF(e.bias_grad(ds1, H, G(f.bo), M, H, acc));
+    RET_IF(e.linear_wgrad(ds1, H, a.ctx, H, G(f.wo), M, H, H, acc));
+    void* dctx = bB;
+    RET_IF(e.linear_dgrad(ds1, H, W(f.wo), dctx, H, M, H, H));
+    void* dqkv = ws.bufQ;
+    RET_IF(attention_bwd(aimpl, a.qkv, mask, dctx, dqkv, ws.attnws, B, S, c.heads, 64, st));
+    RET_IF(e.bias_grad(dqkv, 3 * H, G(f.bqkv), M, 3 * H, acc));
+    RET_IF(e.linear_wgrad(dqkv, 3 * H, xin, H, G(f.wqkv), M, 3 * H, H, acc));
+    void* dx = bC;
+    RET_IF(e.linear_dgrad(dqkv, 3 * H, W(f.wqkv), dx, H, M, 3 * H, H, nullptr, 0, ds1, H));  // + residual branch
+    // rotate: dx becomes the next layer's dOut
+    void* t = dOut; dOut = bC; bC = t;
+  }
+  // embeddings
+  void* de = bB;
+  RET_IF(layernorm_bwd(c.dtype, dOut, ws.e, ws.mean0, ws.rstd0, P(lay.lnw), de, G(lay.lnw), G(lay.lnb), acc, ws.lnws, M, H, st));
+  if (!acc && c.type_vocab > 1 &&
+      hipMemsetAsync(G(lay.type) + H, 0, (size_t)(c.type_vocab - 1) * H * sizeof(float), st) != hipSuccess)
+    return MMSA_ERR_LAUNCH;
+  RET_IF(embed_backward(c.dtype, (const long long*)ids, de, G(lay.word), G(lay.pos), G(lay.type), acc, ws.colws, B, S, H,
+                        c.vocab, c.max_pos, st));
+  return MMSA_OK;
+}
+
+}  // extern "C"

@@ -3,6 +3,9 @@
 #include "../../include/mmsa.h"
 #include "ops.h"
 
+int gemm_prof_begin(int max_records);
+int gemm_prof_end(double* total_ms, double* total_flop, long* launches);
+
 static GemmParams to_params(const mmsa_gemm_desc* d) {
   GemmParams p;
   p.A = d->A; p.B = d->B; p.C = d->C;
@@ -76,6 +79,30 @@ int mmsa_attention_bwd(int32_t impl, const void* qkv, const float* mask, const v
                        int32_t B, int32_t S, int32_t heads, int32_t head_dim, void* stream) {
   if (!qkv || !dctx || !dqkv || !ws || B <= 0 || S <= 0 || heads <= 0) return MMSA_ERR_ARG;
   return attention_bwd(impl, qkv, mask, dctx, dqkv, ws, B, S, heads, head_dim, (hipStream_t)stream);
+}
+
+size_t mmsa_grad_norm_ws_bytes(void) { return grad_norm_ws_bytes(); }
+int mmsa_grad_norm(const float* g, int64_t n, float grad_scale, float max_norm, float* norm_out, void* ws, void* stream) {
+  if (!g || !norm_out || !ws || n <= 0) return MMSA_ERR_ARG;
+  return grad_norm(g, n, grad_scale, max_norm, norm_out, ws, (hipStream_t)stream);
+}
+int mmsa_adamw_step(float* w, const float* g, float* m, float* v, void* w16, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int32_t step, const float* norm_clip, float grad_scale, void* stream) {
+  if (!w || !g || !m || !v) return MMSA_ERR_ARG;
+  return adamw_step(w, g, m, v, w16, n, lr, beta1, beta2, eps, weight_decay, step, norm_clip, grad_scale, (hipStream_t)stream);
+}
+int mmsa_cast_f32(int32_t dtype, const float* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst) return MMSA_ERR_ARG;
+  return cast_f32(dtype, src, dst, n, (hipStream_t)stream);
+}
+
+int mmsa_prof_begin(int32_t max_records) { return gemm_prof_begin(max_records); }
+int mmsa_prof_end(double* total_ms, double* total_flop, int64_t* launches) {
+  if (!total_ms || !total_flop || !launches) return MMSA_ERR_ARG;
+  long n = 0;
+  const int rc = gemm_prof_end(total_ms, total_flop, &n);
+  *launches = n;
+  return rc;
 }
 
 }  // extern "C"

@@ -1,0 +1,128 @@
+// Helpers shared by the encoder / head engines: Linear forward, data gradient, weight gradient and bias gradient
+// expressed on the GEMM descriptor, a bump allocator for caller-provided workspaces, and parameter tables.
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "ops.h"
+
+#define RET_IF(x)            \
+  do {                       \
+    const int _rc = (x);     \
+    if (_rc) return _rc;     \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Bump {  // carves a caller-provided buffer; with base == nullptr it only measures
+  char* base;
+  size_t off;
+  explicit Bump(void* b) : base((char*)b), off(0) {}
+  void* take(size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  }
+};
+
+struct ParamEntry {
+  std::string name;
+  long offset;  // elements into the flat fp32 parameter (and gradient, and working-copy) buffer
+  int ndim;
+  long shape[4];
+  long numel() const {
+    long n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    return n;
+  }
+};
+
+struct ParamTable {
+  std::vector<ParamEntry> entries;
+  long total = 0;
+  long add(const std::string& name, std::initializer_list<long> shape) {
+    ParamEntry e;
+    e.name = name;
+    e.offset = total;
+    e.ndim = (int)shape.size();
+    int i = 0;
+    for (long s : shape) e.shape[i++] = s;
+    for (; i < 4; ++i) e.shape[i] = 1;
+    entries.push_back(e);
+    total += (long)align_up((size_t)e.numel(), 64);  // 64-element alignment: 16-byte aligned in bf16 and fp32
+    return e.offset;
+  }
+};
+
+struct Eng {
+  int dtype;  // MMSA_F32 / MMSA_BF16 storage
+  hipStream_t st;
+  float* splitk_ws;
+  size_t splitk_bytes;
+  float* col_ws;  // colsum partials
+
+  size_t esz() const { return dtype == MMSA_BF16 ? 2 : 4; }
+  // MMSA_BF16_SIMT=1 (diagnostic): run the bf16 path on the SIMT kernels — same storage rounding, independent code —
+  // so the MFMA engines can be cross-checked end to end on the device.
+  static bool force_simt() {
+    const char* v = getenv("MMSA_BF16_SIMT");  // read per call so a test can toggle it inside one process
+    return v && atoi(v) != 0;
+  }
+  int gemm(const GemmParams& p) const {
+    if (dtype != MMSA_BF16) return gemm_f32_launch(p, st);
+    return force_simt() ? gemm_bf16_simt_launch(p, st) : gemm_bf16_launch(p, st);
+  }
+  int attn_impl() const { return dtype != MMSA_BF16 ? 0 : (force_simt() ? 2 : 1); }
+
+  static GemmParams blank() {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.split_k = 1;
+    return p;
+  }
+
+  // y[M,N] = act(x[M,K] W[N,K]^T + bias) (+ add)
+  int linear_fwd(const void* x, long ldx, const void* W, const float* bias, void* y, long ldy, int M, int N, int K,
+                 int act = MMSA_ACT_NONE, void* pre = nullptr, const void* add = nullptr, long ldadd = 0,
+                 int out_f32 = 0) const {
+    GemmParams p = blank();
+    p.A = x; p.lda = ldx; p.B = W; p.ldb = K; p.C = y; p.ldc = ldy;
+    p.M = M; p.N = N; p.K = K;
+    p.bias = bias; p.act = act; p.C2 = pre; p.ldc2 = N; p.add = add; p.ldadd = ldadd; p.out_f32 = out_f32;
+    return gemm(p);
+  }
+  // dx[M,K] = dy[M,N] W[N,K]  (* gelu'(mul)) (+ add)
+  int linear_dgrad(const void* dy, long lddy, const void* W, void* dx, long lddx, int M, int N, int K,
+                   const void* mul = nullptr, long ldmul = 0, const void* add = nullptr, long ldadd = 0) const {
+    GemmParams p = blank();
+    p.A = dy; p.lda = lddy; p.B = W; p.ldb = K; p.b_kmajor = 1; p.C = dx; p.ldc = lddx;
+    p.M = M; p.N = K; p.K = N;
+    p.mul = mul; p.ldmul = ldmul; p.add = add; p.ldadd = ldadd;
+    return gemm(p);
+  }
+  int pick_split(int Mo, int No, int Kred) const {
+    const int tile = dtype == MMSA_BF16 ? 128 : 64;
+    const long tiles = (long)cdiv(Mo, tile) * cdiv(No, tile);
+    int split = (int)(512 / (tiles > 0 ? tiles : 1));
+    const int maxs = Kred / 256;
+    if (split > maxs) split = maxs;
+    if (split > 64) split = 64;
+    if (split < 1) split = 1;
+    while (split > 1 && (size_t)split * Mo * No * sizeof(float) > splitk_bytes) --split;
+    return split;
+  }
+  // dW[N,K] (+)= dy[M,N]^T x[M,K]   (fp32 gradient)
+  int linear_wgrad(const void* dy, long lddy, const void* x, long ldx, float* dW, int M, int N, int K, int accumulate) const {
+    GemmParams p = blank();
+    p.A = dy; p.lda = lddy; p.a_kmajor = 1; p.B = x; p.ldb = ldx; p.b_kmajor = 1; p.C = dW; p.ldc = K;
+    p.M = N; p.N = K; p.K = M;
+    p.out_f32 = 1; p.accumulate = accumulate;
+    p.split_k = pick_split(N, K, M);
+    p.ws = splitk_ws;
+    return gemm(p);
+  }
+  int bias_grad(const void* dy, long lddy, float* db, int M, int N, int accumulate) const {
+    return colsum(dtype, dy, lddy, db, accumulate, col_ws, M, N, st);
+  }
+};

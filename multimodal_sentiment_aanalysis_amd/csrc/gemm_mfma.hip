@@ -12,6 +12,7 @@
 //
 // Implicit-GEMM convolution gathers are resolved per 16-byte chunk at staging time: an invalid chunk (padding,
 // stride hole, row/col/k past the end) is redirected to a page of zeros, so the main loop is branch-free.
+#include <vector>
 #include "gemm.h"
 #include "gemm_epilogue.h"
 
@@ -334,7 +335,53 @@ static int launch_variant(const GemmParams& p, hipStream_t st) {
   return MMSA_OK;
 }
 
+// ---- optional live timing of the MFMA GEMM launches (bench.py roofline): HIP events on the launch stream ----------
+struct ProfRec { hipEvent_t a, b; double flop; };
+static std::vector<ProfRec> g_prof;
+static size_t g_prof_used = 0;
+static bool g_prof_on = false;
+
+int gemm_prof_begin(int max_records) {
+  if (max_records < 0) return MMSA_ERR_ARG;
+  while (g_prof.size() < (size_t)max_records) {
+    ProfRec r;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return MMSA_ERR_LAUNCH;
+    r.flop = 0;
+    g_prof.push_back(r);
+  }
+  g_prof_used = 0;
+  g_prof_on = true;
+  return MMSA_OK;
+}
+// caller must have synchronized the stream(s); returns summed kernel time, algorithmic flop and launch count
+int gemm_prof_end(double* total_ms, double* total_flop, long* launches) {
+  g_prof_on = false;
+  double ms = 0, fl = 0;
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) return MMSA_ERR_LAUNCH;
+    ms += t;
+    fl += g_prof[i].flop;
+  }
+  *total_ms = ms; *total_flop = fl; *launches = (long)g_prof_used;
+  g_prof_used = 0;
+  return MMSA_OK;
+}
+
+static int gemm_bf16_launch_inner(const GemmParams& pin, hipStream_t st);
+
 int gemm_bf16_launch(const GemmParams& pin, hipStream_t st) {
+  if (!g_prof_on || g_prof_used >= g_prof.size()) return gemm_bf16_launch_inner(pin, st);
+  ProfRec& r = g_prof[g_prof_used];
+  r.flop = 2.0 * pin.M * pin.N * (double)pin.K;
+  (void)hipEventRecord(r.a, st);
+  const int rc = gemm_bf16_launch_inner(pin, st);
+  (void)hipEventRecord(r.b, st);
+  ++g_prof_used;
+  return rc;
+}
+
+static int gemm_bf16_launch_inner(const GemmParams& pin, hipStream_t st) {
   GemmParams p = pin;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MMSA_ERR_ARG;
   if (p.N % 4) return MMSA_ERR_ARG;

@@ -27,3 +27,58 @@ int attention_fwd(int impl, const void* qkv, const float* mask, void* ctx, int B
                   hipStream_t st);
 int attention_bwd(int impl, const void* qkv, const float* mask, const void* dctx, void* dqkv, float* ws, int B, int S,
                   int heads, int head_dim, hipStream_t st);
+int tanh_bwd(int dtype, const void* dy, const void* y, void* dx, long n, hipStream_t st);
+
+// bnops.hip
+size_t bn_ws_bytes(int C);
+int bn_forward(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+               float* mean, float* invstd, const void* res, void* y, float* ws, int M, int C, float eps, float momentum,
+               int act, int training, hipStream_t st);
+int bn_backward(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
+                const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
+                float* ws, int M, int C, int act, int training, hipStream_t st);
+
+// poolops.hip
+int stem_im2col(int dtype, const float* img, void* col, int B, int Cin, int H, int W, int OH, int OW, int KH, int KW,
+                int stride, int pad, int Kpad, hipStream_t st);
+int maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int B, int H, int W, int C, hipStream_t st);
+int maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, void* dx, int B, int H, int W, int C, hipStream_t st);
+int avgpool_fwd(int dtype, const void* x, void* y, int B, int HW, int C, hipStream_t st);
+int avgpool_bwd(int dtype, const void* dy, void* dx, int B, int HW, int C, hipStream_t st);
+int cast_f32(int dtype, const float* src, void* dst, long n, hipStream_t st);
+int pad_rows(int dtype, const float* src, void* dst, int rows, int cols_src, int cols_dst, hipStream_t st);
+int unpad_rows(const float* src, float* dst, int rows, int cols_src, int cols_dst, int accumulate, hipStream_t st);
+
+// headops.hip (fp32)
+int l2norm_fwd(const float* x, float* y, float* nrm, int M, int E, float eps, hipStream_t st);
+int l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int M, int E, float eps, int accumulate,
+               hipStream_t st);
+int mha_core_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* ctx, long ldc,
+                 float* probs, int B, int Lq, int Lk, int E, int heads, hipStream_t st);
+int mha_core_bwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, const float* probs,
+                 const float* dctx, long ldc, float* dq, long lddq, float* dk, long lddk, float* dv, long lddv, int B,
+                 int Lq, int Lk, int E, int heads, hipStream_t st);
+int seq_pool_fwd(const float* x, float* y, unsigned char* idx, int B, int L, int E, int mode, hipStream_t st);
+int seq_pool_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int L, int E, int mode, hipStream_t st);
+int gate_mix_fwd(const float* g, const float* q, long ldq, const float* a, long lda, float* mix, int B, int E, hipStream_t st);
+int gate_mix_bwd(const float* dmix, const float* g, const float* q, long ldq, const float* a, long lda, float* dq, float* da,
+                 float* dgpre, int B, int E, hipStream_t st);
+int weighted_concat_fwd(const float* wl, const float* f1, const float* f2, const float* f3, float* w, float* out, int B, int E,
+                        hipStream_t st);
+int weighted_concat_bwd(const float* dout, const float* w, const float* f1, const float* f2, const float* f3, float* df1,
+                        float* df2, float* df3, float* dwl, int B, int E, hipStream_t st);
+int ce_fwd_bwd(const float* logits, const long long* labels, float* loss, float* dlogits, float* probs, int B, int C,
+               float grad_scale, hipStream_t st);
+int dropout_fwd(const float* x, float* y, unsigned char* mask, long n, float p, unsigned long long seed, hipStream_t st);
+int dropout_bwd(const float* dy, const unsigned char* mask, float* dx, long n, float p, hipStream_t st);
+#define EW_COPY 0
+#define EW_ADD 1
+#define EW_RELU_BWD 2
+#define EW_GELU_BWD 3
+int ew2d(int op, const float* a, long lda, const float* b, long ldb, float* out, long ldo, int rows, int cols, hipStream_t st);
+
+// optim.hip
+size_t grad_norm_ws_bytes();
+int grad_norm(const float* g, long n, float grad_scale, float max_norm, float* norm_out, void* ws, hipStream_t st);
+int adamw_step(float* w, const float* g, float* m, float* v, void* w16, long n, float lr, float b1, float b2, float eps,
+               float wd, int step, const float* norm_clip, float grad_scale, hipStream_t st);

@@ -1,0 +1,95 @@
+// Step tail of the reference trainer as two kernels over the flat parameter / gradient buffers:
+//   torch.nn.utils.clip_grad_norm_(params, 1.0)  (Trainer.py:80)  -> grad_sumsq (two-stage, order-fixed)
+//   optim.AdamW(lr 1e-4, weight_decay 0.01).step() (Trainer.py:19-21,81) -> adamw_step (also refreshes the
+//   bf16 working copy of the weights in the same pass, so no separate cast is needed).
+// HBM-bound: 16 B/param read (w, g, m, v) + 12-14 B/param written. The clip coefficient is computed on the
+// device from the norm (no host sync); `grad_scale` folds the 1/world_size of the data-parallel average in.
+#include "common.h"
+#include "ops.h"
+
+#define SUMSQ_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void grad_sumsq_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ part) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = *(const f32x4*)(g + i * 4);
+    acc += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; acc += (double)v * v; }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// norm_out[0] = grad_scale * sqrt(sum); norm_out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))
+__global__ void grad_norm_finalize_kernel(const double* __restrict__ part, int nblk, float grad_scale, float max_norm,
+                                          float* __restrict__ norm_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += part[i];
+  const float norm = (float)(sqrt(s) * (double)grad_scale);
+  norm_out[0] = norm;
+  norm_out[1] = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+}
+
+size_t grad_norm_ws_bytes() { return SUMSQ_BLOCKS * sizeof(double); }
+
+int grad_norm(const float* g, long n, float grad_scale, float max_norm, float* norm_out, void* ws, hipStream_t st) {
+  const int blocks = (int)min((n / 4 + 255) / 256 + 1, (long)SUMSQ_BLOCKS);
+  hipLaunchKernelGGL(grad_sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, g, n, (double*)ws);
+  hipLaunchKernelGGL(grad_norm_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, blocks, grad_scale, max_norm,
+                     norm_out);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+// torch.optim.AdamW (decoupled weight decay on every parameter, bias-corrected):
+//   w *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; w -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16* __restrict__ w16, long n, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    const float* __restrict__ norm_clip, float grad_scale) {
+  const float coef = (norm_clip ? norm_clip[1] : 1.f) * grad_scale;
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 wv = *(const f32x4*)(w + i * 4), mv = *(const f32x4*)(m + i * 4), vv = *(const f32x4*)(v + i * 4);
+    const f32x4 gv = *(const f32x4*)(g + i * 4) * coef;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      wv[e] *= 1.f - lr * wd;
+      mv[e] = b1 * mv[e] + (1.f - b1) * gv[e];
+      vv[e] = b2 * vv[e] + (1.f - b2) * gv[e] * gv[e];
+      wv[e] -= (lr / bc1) * mv[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
+    }
+    *(f32x4*)(w + i * 4) = wv;
+    *(f32x4*)(m + i * 4) = mv;
+    *(f32x4*)(v + i * 4) = vv;
+    if (w16) {
+      bf16x4 t = {(bf16)wv[0], (bf16)wv[1], (bf16)wv[2], (bf16)wv[3]};
+      *(bf16x4*)(w16 + i * 4) = t;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = n4 * 4 + threadIdx.x;
+    float wv = w[i] * (1.f - lr * wd);
+    const float gv = g[i] * coef;
+    const float mv = b1 * m[i] + (1.f - b1) * gv, vv = b2 * v[i] + (1.f - b2) * gv * gv;
+    wv -= (lr / bc1) * mv / (sqrtf(vv) / bc2_sqrt + eps);
+    w[i] = wv; m[i] = mv; v[i] = vv;
+    if (w16) w16[i] = (bf16)wv;
+  }
+}
+
+int adamw_step(float* w, const float* g, float* m, float* v, void* w16, long n, float lr, float b1, float b2, float eps,
+               float wd, int step, const float* norm_clip, float grad_scale, hipStream_t st) {
+  if (n <= 0 || step < 1) return MMSA_ERR_ARG;
+  const float bc1 = 1.f - powf(b1, (float)step);
+  const float bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
+  const int blocks = (int)min((n / 4 + 255) / 256 + 1, 4096L);
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, w, g, m, v, (bf16*)w16, n, lr, b1, b2, eps, wd, bc1,
+                     bc2_sqrt, norm_clip, grad_scale);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}

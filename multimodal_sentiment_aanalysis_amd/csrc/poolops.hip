@@ -1,0 +1,247 @@
+// Layout / pooling kernels of the ResNet side (all HBM-bound, NHWC, 4-channel vector accesses):
+// stem im2col straight from the NCHW fp32 image, 3x3/2 max-pool with saved argmax, global average pool,
+// storage casts of the working weights, and small copies.
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "ops.h"
+
+// col[m][k], m = (b, oy, ox), k = (ky*KW + kx)*Cin + ci for k < KH*KW*Cin, zero for the padding up to Kpad
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ img, T* __restrict__ col, int B, int Cin,
+                                                          int H, int W, int OH, int OW, int KH, int KW, int stride, int pad,
+                                                          int Kpad) {
+  const int kch = Kpad / 4;
+  const long total = (long)B * OH * OW * kch;
+  const int Kreal = KH * KW * Cin;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / kch;
+    const int k0 = (int)(i - m * kch) * 4;
+    const int ox = (int)(m % OW);
+    const long t = m / OW;
+    const int oy = (int)(t % OH), b = (int)(t / OH);
+    f32x4 v = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + e;
+      if (k < Kreal) {
+        const int ci = k % Cin, tap = k / Cin;
+        const int kx = tap % KW, ky = tap / KW;
+        const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[e] = img[(((long)b * Cin + ci) * H + iy) * W + ix];
+      }
+    }
+    Vec4<T>::store(col + m * Kpad + k0, v);
+  }
+}
+
+int stem_im2col(int dtype, const float* img, void* col, int B, int Cin, int H, int W, int OH, int OW, int KH, int KW,
+                int stride, int pad, int Kpad, hipStream_t st) {
+  if (Kpad % 4) return MMSA_ERR_ARG;
+  const long total = (long)B * OH * OW * (Kpad / 4);
+  const int grid = (int)min((total + 255) / 256, 8192L);
+  if (dtype == MMSA_BF16)
+    hipLaunchKernelGGL(stem_im2col_kernel<bf16>, dim3(grid), dim3(256), 0, st, img, (bf16*)col, B, Cin, H, W, OH, OW, KH,
+                       KW, stride, pad, Kpad);
+  else
+    hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(grid), dim3(256), 0, st, img, (float*)col, B, Cin, H, W, OH, OW, KH,
+                       KW, stride, pad, Kpad);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ max pool 3x3/2 pad 1
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          unsigned char* __restrict__ idx, int B, int H, int W, int C, int OH,
+                                                          int OW) {
+  const int c4n = C / 4;
+  const long total = (long)B * OH * OW * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const long m = i / c4n;
+    const int ox = (int)(m % OW);
+    const long t = m / OW;
+    const int oy = (int)(t % OH), b = (int)(t / OH);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    bool first = true;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 + kx - 1;
+        if (ix < 0 || ix >= W) continue;
+        const f32x4 v = Vec4<T>::load(x + (((long)b * H + iy) * W + ix) * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (first || v[e] > best[e]) { best[e] = v[e]; bi[e] = ky * 3 + kx; }
+        first = false;
+      }
+    }
+    Vec4<T>::store(y + m * C + c, best);
+    *(uchar4*)(idx + m * C + c) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                          T* __restrict__ dx, int B, int H, int W, int C, int OH, int OW) {
+  const int c4n = C / 4;
+  const long total = (long)B * H * W * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const long m = i / c4n;
+    const int ix = (int)(m % W);
+    const long t = m / W;
+    const int iy = (int)(t % H), b = (int)(t / H);
+    f32x4 g = {0, 0, 0, 0};
+    // output rows whose window [2oy-1, 2oy+1] contains iy
+    const int oy_lo = iy / 2, oy_hi = (iy + 1) / 2;
+    const int ox_lo = ix / 2, ox_hi = (ix + 1) / 2;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      if (oy >= OH) continue;
+      const int ky = iy - (2 * oy - 1);
+      if (ky < 0 || ky > 2) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        if (ox >= OW) continue;
+        const int kx = ix - (2 * ox - 1);
+        if (kx < 0 || kx > 2) continue;
+        const long om = ((long)b * OH + oy) * OW + ox;
+        const uchar4 id = *(const uchar4*)(idx + om * C + c);
+        const f32x4 d = Vec4<T>::load(dy + om * C + c);
+        const int tap = ky * 3 + kx;
+        if (id.x == tap) g[0] += d[0];
+        if (id.y == tap) g[1] += d[1];
+        if (id.z == tap) g[2] += d[2];
+        if (id.w == tap) g[3] += d[3];
+      }
+    }
+    Vec4<T>::store(dx + m * C + c, g);
+  }
+}
+
+int maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int B, int H, int W, int C, hipStream_t st) {
+  if (C % 4) return MMSA_ERR_ARG;
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long total = (long)B * OH * OW * (C / 4);
+  const int grid = (int)min((total + 255) / 256, 8192L);
+  if (dtype == MMSA_BF16)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)y, idx, B, H, W, C, OH,
+                       OW);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, idx, B, H, W, C,
+                       OH, OW);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+int maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, void* dx, int B, int H, int W, int C, hipStream_t st) {
+  if (C % 4) return MMSA_ERR_ARG;
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long total = (long)B * H * W * (C / 4);
+  const int grid = (int)min((total + 255) / 256, 8192L);
+  if (dtype == MMSA_BF16)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy, idx, (bf16*)dx, B, H, W, C,
+                       OH, OW);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, idx, (float*)dx, B, H, W,
+                       C, OH, OW);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ global average pool
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int HW, int C) {
+  const int c4n = C / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * c4n) return;
+  const int b = (int)(i / c4n), c = (int)(i % c4n) * 4;
+  f32x4 s = {0, 0, 0, 0};
+  for (int p = 0; p < HW; ++p) s += Vec4<T>::load(x + ((long)b * HW + p) * C + c);
+  Vec4<T>::store(y + (long)b * C + c, s * (1.0f / (float)HW));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int HW, int C) {
+  const int c4n = C / 4;
+  const long total = (long)B * HW * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const long bp = i / c4n;
+    const int b = (int)(bp / HW);
+    Vec4<T>::store(dx + bp * C + c, Vec4<T>::load(dy + (long)b * C + c) * (1.0f / (float)HW));
+  }
+}
+int avgpool_fwd(int dtype, const void* x, void* y, int B, int HW, int C, hipStream_t st) {
+  if (C % 4) return MMSA_ERR_ARG;
+  const int grid = cdiv((long)B * (C / 4), 256);
+  if (dtype == MMSA_BF16)
+    hipLaunchKernelGGL(avgpool_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)y, B, HW, C);
+  else
+    hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, B, HW, C);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+int avgpool_bwd(int dtype, const void* dy, void* dx, int B, int HW, int C, hipStream_t st) {
+  if (C % 4) return MMSA_ERR_ARG;
+  const long total = (long)B * HW * (C / 4);
+  const int grid = (int)min((total + 255) / 256, 8192L);
+  if (dtype == MMSA_BF16)
+    hipLaunchKernelGGL(avgpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy, (bf16*)dx, B, HW, C);
+  else
+    hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (float*)dx, B, HW, C);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ casts / copies
+// dst[i] = (T) src[i]  (n % 4 == 0 handled by the tail loop)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+    Vec4<T>::store(dst + i * 4, *(const f32x4*)(src + i * 4));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = from_f32<T>(src[n4 * 4 + threadIdx.x]);
+}
+int cast_f32(int dtype, const float* src, void* dst, long n, hipStream_t st) {
+  if (n <= 0) return MMSA_OK;
+  const int grid = (int)min((n / 4 + 255) / 256 + 1, 8192L);
+  if (dtype == MMSA_BF16) hipLaunchKernelGGL(cast_f32_kernel<bf16>, dim3(grid), dim3(256), 0, st, src, (bf16*)dst, n);
+  else hipLaunchKernelGGL(cast_f32_kernel<float>, dim3(grid), dim3(256), 0, st, src, (float*)dst, n);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+// dst[r][0:cols_dst] = src[r][0:cols_src] zero-padded (stem weight [64][147] -> [64][Kpad]) in storage type T
+template <typename T>
+__global__ void pad_rows_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols_src, int cols_dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols_dst) return;
+  const int r = i / cols_dst, c = i - r * cols_dst;
+  dst[i] = from_f32<T>(c < cols_src ? src[(long)r * cols_src + c] : 0.f);
+}
+int pad_rows(int dtype, const float* src, void* dst, int rows, int cols_src, int cols_dst, hipStream_t st) {
+  const int grid = cdiv((long)rows * cols_dst, 256);
+  if (dtype == MMSA_BF16)
+    hipLaunchKernelGGL(pad_rows_kernel<bf16>, dim3(grid), dim3(256), 0, st, src, (bf16*)dst, rows, cols_src, cols_dst);
+  else
+    hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(grid), dim3(256), 0, st, src, (float*)dst, rows, cols_src, cols_dst);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+// dst[r][0:cols_dst] (+)= src[r][0:cols_dst] with src row stride cols_src >= cols_dst (stem wgrad un-padding)
+__global__ void unpad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols_src,
+                                  int cols_dst, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols_dst) return;
+  const int r = i / cols_dst, c = i - r * cols_dst;
+  const float v = src[(long)r * cols_src + c];
+  dst[i] = accumulate ? dst[i] + v : v;
+}
+int unpad_rows(const float* src, float* dst, int rows, int cols_src, int cols_dst, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(unpad_rows_kernel, dim3(cdiv((long)rows * cols_dst, 256)), dim3(256), 0, st, src, dst, rows, cols_src,
+                     cols_dst, accumulate);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}

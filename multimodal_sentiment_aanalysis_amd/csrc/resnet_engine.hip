@@ -1,0 +1,390 @@
+// ResNet (bottleneck, v1.5) image encoder engine: whole forward / backward as kernel sequences on the caller's stream.
+//
+// NOT IN THE REFERENCE: ResNet-50 fills the reference's encoder slot (MultimodalModel.py:264-266). Activations are
+// NHWC ([B*H*W][C] matrices); every convolution is an implicit GEMM on the MFMA kernel (1x1 stride 1: plain GEMM;
+// 3x3 and strided 1x1: row gather at staging time; the 7x7 stem: explicit im2col, K padded 147 -> 192);
+// BatchNorm uses batch statistics in training (two-stage column reductions) with the affine + ReLU (+ residual)
+// applied in one streaming kernel. Weights are stored [Cout][KH][KW][Cin] (the physical layout of a channels_last
+// torch tensor of logical shape [Cout][Cin][KH][KW], so state_dicts stay torchvision-compatible).
+#include "../../include/mmsa.h"
+#include <stdlib.h>
+#include "engine_common.h"
+
+struct ConvDef {
+  int Cin, Cout, k, stride, pad, Hin, Win, Hout, Wout;
+  long w, g, b;     // offsets into the flat parameter buffer: weight, bn gamma, bn beta
+  long rm, rv;      // offsets into the flat BN buffer: running mean / var
+};
+struct BlockDef {
+  ConvDef c1, c2, c3, ds;
+  bool has_ds;
+};
+struct ResLayout {
+  ParamTable t;   // parameters
+  ParamTable bt;  // BN running buffers (fp32)
+  ConvDef stem;
+  std::vector<BlockDef> blocks;
+  long wproj, bproj;
+  int feat_c, Hf, Wf;  // final feature map
+  int Kstem_pad;
+};
+
+static ConvDef make_conv(ResLayout& L, const std::string& wname, const std::string& bnname, int Cin, int Cout, int k, int s,
+                         int p, int Hin, int Win) {
+  ConvDef c;
+  c.Cin = Cin; c.Cout = Cout; c.k = k; c.stride = s; c.pad = p; c.Hin = Hin; c.Win = Win;
+  c.Hout = (Hin + 2 * p - k) / s + 1;
+  c.Wout = (Win + 2 * p - k) / s + 1;
+  c.w = L.t.add(wname, {Cout, Cin, k, k});  // logical OIHW; physical [Cout][k][k][Cin]
+  c.g = L.t.add(bnname + ".weight", {Cout});
+  c.b = L.t.add(bnname + ".bias", {Cout});
+  c.rm = L.bt.add(bnname + ".running_mean", {Cout});
+  c.rv = L.bt.add(bnname + ".running_var", {Cout});
+  return c;
+}
+
+static ResLayout res_layout(const mmsa_resnet_cfg& c) {
+  ResLayout L;
+  L.Kstem_pad = 192;
+  L.stem = make_conv(L, "resnet.conv1.weight", "resnet.bn1", 3, 64, 7, 2, 3, c.height, c.width);
+  int H = (L.stem.Hout + 2 - 3) / 2 + 1, W = (L.stem.Wout + 2 - 3) / 2 + 1;  // after the 3x3/2 max-pool
+  int inp = 64;
+  for (int si = 0; si < 4; ++si) {
+    const int w = c.widths[si];
+    for (int b = 0; b < c.blocks[si]; ++b) {
+      const std::string p = "resnet.layer" + std::to_string(si + 1) + "." + std::to_string(b) + ".";
+      const int s = (b == 0 && si > 0) ? 2 : 1;
+      BlockDef B;
+      B.c1 = make_conv(L, p + "conv1.weight", p + "bn1", inp, w, 1, 1, 0, H, W);
+      B.c2 = make_conv(L, p + "conv2.weight", p + "bn2", w, w, 3, s, 1, H, W);
+      B.c3 = make_conv(L, p + "conv3.weight", p + "bn3", w, w * 4, 1, 1, 0, B.c2.Hout, B.c2.Wout);
+      B.has_ds = (b == 0);
+      if (B.has_ds) B.ds = make_conv(L, p + "downsample.0.weight", p + "downsample.1", inp, w * 4, 1, s, 0, H, W);
+      L.blocks.push_back(B);
+      H = B.c2.Hout; W = B.c2.Wout;
+      inp = w * 4;
+    }
+  }
+  L.feat_c = inp; L.Hf = H; L.Wf = W;
+  L.wproj = L.t.add("proj.weight", {c.out_dim, inp});
+  L.bproj = L.t.add("proj.bias", {c.out_dim});
+  return L;
+}
+
+static bool res_cfg_ok(const mmsa_resnet_cfg& c) {
+  if (c.batch <= 0 || c.height < 32 || c.width < 32 || c.out_dim % 64) return false;
+  for (int i = 0; i < 4; ++i)
+    if (c.blocks[i] <= 0 || c.widths[i] % 64) return false;
+  return c.dtype == MMSA_F32 || c.dtype == MMSA_BF16;
+}
+
+struct ConvWs {
+  void *z, *y;  // conv output (pre-BN), BN(+act) output
+  float *mean, *invstd;
+};
+struct BlockWs {
+  ConvWs c1, c2, c3, ds;  // c3.y is the block output relu(bn3 + identity); ds.y the projected identity
+};
+struct ResWs {
+  void *col, *stem_w;
+  ConvWs stem;
+  void* pool;
+  unsigned char* pool_idx;
+  std::vector<BlockWs> blocks;
+  void *pooled, *dfeat_t, *dpooled;
+  void *g0, *g1, *g2, *g3;  // gradient ping-pong buffers (largest activation size)
+  float *stem_dw, *splitk, *colws, *bnws;
+  size_t splitk_bytes;
+  size_t total;
+};
+
+static ConvWs conv_ws(Bump& b, const ConvDef& c, int B, size_t es, bool need_y = true) {
+  ConvWs w;
+  const size_t n = (size_t)B * c.Hout * c.Wout * c.Cout;
+  w.z = b.take(n * es);
+  w.y = need_y ? b.take(n * es) : nullptr;
+  w.mean = (float*)b.take((size_t)c.Cout * 4);
+  w.invstd = (float*)b.take((size_t)c.Cout * 4);
+  return w;
+}
+
+static ResWs res_ws(const mmsa_resnet_cfg& c, const ResLayout& L, void* base) {
+  ResWs w;
+  Bump b(base);
+  const size_t es = c.dtype == MMSA_BF16 ? 2 : 4;
+  const int B = c.batch;
+  const size_t M0 = (size_t)B * L.stem.Hout * L.stem.Wout;
+  w.col = b.take(M0 * L.Kstem_pad * es);
+  w.stem_w = b.take((size_t)64 * L.Kstem_pad * es);
+  w.stem = conv_ws(b, L.stem, B, es);
+  const int PH = (L.stem.Hout + 2 - 3) / 2 + 1, PW = (L.stem.Wout + 2 - 3) / 2 + 1;
+  const size_t np = (size_t)B * PH * PW * 64;
+  w.pool = b.take(np * es);
+  w.pool_idx = (unsigned char*)b.take(np);
+  size_t maxact = M0 * 64;
+  size_t maxw = (size_t)64 * L.Kstem_pad;
+  int maxc = 64;
+  for (const BlockDef& bd : L.blocks) {
+    BlockWs x;
+    x.c1 = conv_ws(b, bd.c1, B, es);
+    x.c2 = conv_ws(b, bd.c2, B, es);
+    x.c3 = conv_ws(b, bd.c3, B, es);
+    if (bd.has_ds) x.ds = conv_ws(b, bd.ds, B, es);
+    w.blocks.push_back(x);
+    const size_t a_in = (size_t)B * bd.c1.Hin * bd.c1.Win * (bd.c1.Cin > bd.c1.Cout ? bd.c1.Cin : bd.c1.Cout);
+    const size_t a_out = (size_t)B * bd.c3.Hout * bd.c3.Wout * bd.c3.Cout;
+    if (a_in > maxact) maxact = a_in;
+    if (a_out > maxact) maxact = a_out;
+    const size_t w2 = (size_t)bd.c2.Cout * 9 * bd.c2.Cin, w3 = (size_t)bd.c3.Cout * bd.c3.Cin;
+    if (w2 > maxw) maxw = w2;
+    if (w3 > maxw) maxw = w3;
+    if (bd.has_ds && (size_t)bd.ds.Cout * bd.ds.Cin > maxw) maxw = (size_t)bd.ds.Cout * bd.ds.Cin;
+    if (bd.c3.Cout > maxc) maxc = bd.c3.Cout;
+  }
+  w.pooled = b.take((size_t)B * L.feat_c * es);
+  w.dfeat_t = b.take((size_t)B * c.out_dim * es);
+  w.dpooled = b.take((size_t)B * L.feat_c * es);
+  w.g0 = b.take(maxact * es);
+  w.g1 = b.take(maxact * es);
+  w.g2 = b.take(maxact * es);
+  w.g3 = b.take(maxact * es);
+  w.stem_dw = (float*)b.take((size_t)64 * L.Kstem_pad * 4);
+  // split-K slabs for the weight gradients: up to 64 slabs of the small early-stage weights, fewer of the large ones
+  w.splitk_bytes = (size_t)16 * maxw * sizeof(float);
+  w.splitk = (float*)b.take(w.splitk_bytes);
+  w.colws = (float*)b.take(colsum_ws_bytes(maxc > c.out_dim ? maxc : c.out_dim));
+  w.bnws = (float*)b.take(bn_ws_bytes(maxc));
+  w.total = b.off;
+  return w;
+}
+
+struct ResCtx {
+  const mmsa_resnet_cfg& c;
+  Eng e;
+  const float* w32;
+  const void* wt;
+  float* bnbuf;
+  float* grad;
+  int acc;
+  size_t es;
+  const void* W(long off) const { return (const char*)wt + (size_t)off * es; }
+  const float* P(long off) const { return w32 + off; }
+  float* G(long off) const { return grad + off; }
+};
+
+static void set_geom(ConvGeom& g, int SH, int SW, int GH, int GW, int k, int mul, int kmul, int off, int div, int cper) {
+  g.SH = SH; g.SW = SW; g.GH = GH; g.GW = GW; g.KH = k; g.KW = k;
+  g.mul = mul; g.kmul = kmul; g.off = off; g.div = div; g.cper = cper; g.src_pix_stride = cper;
+  g.fd_gw = make_fastdiv(GW); g.fd_ghw = make_fastdiv(GH * GW); g.fd_kw = make_fastdiv(k); g.fd_cper = make_fastdiv(cper);
+}
+
+// z[B*Ho*Wo][Cout] = conv(x)
+static int conv_fwd(const ResCtx& r, const ConvDef& c, const void* x, void* z) {
+  const int B = r.c.batch, M = B * c.Hout * c.Wout, K = c.k * c.k * c.Cin;
+  GemmParams p = Eng::blank();
+  p.A = x; p.lda = c.Cin; p.B = r.W(c.w); p.ldb = K; p.C = z; p.ldc = c.Cout;
+  p.M = M; p.N = c.Cout; p.K = K;
+  if (!(c.k == 1 && c.stride == 1)) {
+    p.gather = 1;
+    set_geom(p.g, c.Hin, c.Win, c.Hout, c.Wout, c.k, c.stride, 1, -c.pad, 1, c.Cin);
+  }
+  return r.e.gemm(p);
+}
+// dx[B*Hi*Wi][Cin] = conv_transpose(dz) (+ add)
+static int conv_dgrad(const ResCtx& r, const ConvDef& c, const void* dz, void* dx, const void* add) {
+  const int B = r.c.batch, M = B * c.Hin * c.Win, K = c.k * c.k * c.Cout;
+  GemmParams p = Eng::blank();
+  p.A = dz; p.lda = c.Cout; p.B = r.W(c.w); p.ldb = (long)c.k * c.k * c.Cin; p.b_kmajor = 1; p.C = dx; p.ldc = c.Cin;
+  p.M = M; p.N = c.Cin; p.K = K;
+  p.add = add; p.ldadd = c.Cin;
+  if (!(c.k == 1 && c.stride == 1)) {
+    p.gather = 1;
+    p.b_tap_stride = c.Cin;
+    set_geom(p.g, c.Hout, c.Wout, c.Hin, c.Win, c.k, 1, -1, c.pad, c.stride, c.Cout);
+  }
+  return r.e.gemm(p);
+}
+// dW[Cout][k*k*Cin] (+)= dz^T gathered(x)
+static int conv_wgrad(const ResCtx& r, const ConvDef& c, const void* dz, const void* x, float* dW, int accumulate) {
+  const int B = r.c.batch, Kred = B * c.Hout * c.Wout, N = c.k * c.k * c.Cin;
+  GemmParams p = Eng::blank();
+  p.A = dz; p.lda = c.Cout; p.a_kmajor = 1; p.B = x; p.ldb = c.Cin; p.b_kmajor = 1; p.C = dW; p.ldc = N;
+  p.M = c.Cout; p.N = N; p.K = Kred;
+  p.out_f32 = 1; p.accumulate = accumulate;
+  if (!(c.k == 1 && c.stride == 1)) {
+    p.gather = 2;
+    set_geom(p.g, c.Hin, c.Win, c.Hout, c.Wout, c.k, c.stride, 1, -c.pad, 1, c.Cin);
+  }
+  p.split_k = r.e.pick_split(c.Cout, N, Kred);
+  p.ws = r.e.splitk_ws;
+  return r.e.gemm(p);
+}
+
+static int bn_fwd(const ResCtx& r, const ConvDef& c, const ConvWs& w, const void* res, void* y, int act, float* bnws) {
+  const int M = r.c.batch * c.Hout * c.Wout;
+  return bn_forward(r.c.dtype, w.z, r.P(c.g), r.P(c.b), r.bnbuf + c.rm, r.bnbuf + c.rv, w.mean, w.invstd, res, y, bnws, M,
+                    c.Cout, r.c.bn_eps, r.c.bn_momentum, act, r.c.training, r.e.st);
+}
+static int bn_bwd(const ResCtx& r, const ConvDef& c, const ConvWs& w, const void* dy, const void* y, void* dz, void* dres,
+                  int act, float* bnws) {
+  const int M = r.c.batch * c.Hout * c.Wout;
+  return bn_backward(r.c.dtype, dy, w.z, y, w.mean, w.invstd, r.P(c.g), r.P(c.b), dz, dres, r.G(c.g), r.G(c.b), r.acc, bnws,
+                     M, c.Cout, act, r.c.training, r.e.st);
+}
+
+extern "C" {
+
+int mmsa_resnet_param_count(const mmsa_resnet_cfg* c, int32_t buffers) {
+  if (!c || !res_cfg_ok(*c)) return -1;
+  const ResLayout L = res_layout(*c);
+  return (int)(buffers ? L.bt.entries.size() : L.t.entries.size());
+}
+int64_t mmsa_resnet_param_total(const mmsa_resnet_cfg* c, int32_t buffers) {
+  if (!c || !res_cfg_ok(*c)) return -1;
+  const ResLayout L = res_layout(*c);
+  return buffers ? L.bt.total : L.t.total;
+}
+int mmsa_resnet_param_info(const mmsa_resnet_cfg* c, int32_t buffers, int idx, char* name, int name_cap, int64_t* offset,
+                           int32_t* ndim, int64_t* shape) {
+  if (!c || !res_cfg_ok(*c)) return MMSA_ERR_ARG;
+  const ResLayout L = res_layout(*c);
+  const ParamTable& t = buffers ? L.bt : L.t;
+  if (idx < 0 || idx >= (int)t.entries.size()) return MMSA_ERR_ARG;
+  const ParamEntry& e = t.entries[idx];
+  if ((int)e.name.size() + 1 > name_cap) return MMSA_ERR_ARG;
+  strcpy(name, e.name.c_str());
+  *offset = e.offset;
+  *ndim = e.ndim;
+  for (int i = 0; i < 4; ++i) shape[i] = e.shape[i];
+  return MMSA_OK;
+}
+// Test/diagnostic aid: byte offset inside the workspace of a saved tensor. block = -1: stem (which 0 = conv out z,
+// 1 = BN+ReLU out y, 2 = pooled); block >= 0: which 0..7 = c1.z, c1.y, c2.z, c2.y, c3.z, c3.y(block output), ds.z, ds.y;
+// block = -2: which 0..3 = gradient ping-pong buffers g0..g3. Returns -1 when absent.
+int64_t mmsa_resnet_ws_offset(const mmsa_resnet_cfg* c, int32_t block, int32_t which) {
+  if (!c || !res_cfg_ok(*c)) return -1;
+  const ResLayout L = res_layout(*c);
+  char* base = (char*)0x100000;
+  ResWs ws = res_ws(*c, L, base);
+  const void* p = nullptr;
+  if (block == -1) p = which == 0 ? ws.stem.z : which == 1 ? ws.stem.y : which == 2 ? ws.pool : nullptr;
+  else if (block == -2) p = which == 0 ? ws.g0 : which == 1 ? ws.g1 : which == 2 ? ws.g2 : which == 3 ? ws.g3 : nullptr;
+  else if (block >= 0 && block < (int)ws.blocks.size()) {
+    const BlockWs& b = ws.blocks[block];
+    const void* t[8] = {b.c1.z, b.c1.y, b.c2.z, b.c2.y, b.c3.z, b.c3.y, L.blocks[block].has_ds ? b.ds.z : nullptr,
+                        L.blocks[block].has_ds ? b.ds.y : nullptr};
+    if (which >= 0 && which < 8) p = t[which];
+  }
+  return p ? (int64_t)((const char*)p - base) : -1;
+}
+
+size_t mmsa_resnet_ws_bytes(const mmsa_resnet_cfg* c) {
+  if (!c || !res_cfg_ok(*c)) return 0;
+  const ResLayout L = res_layout(*c);
+  return res_ws(*c, L, nullptr).total;
+}
+
+int mmsa_resnet_fwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt, float* bnbuf, const float* image,
+                    void* ws_base, float* feat, void* stream) {
+  if (!cp || !res_cfg_ok(*cp) || !w32 || !wt || !bnbuf || !image || !ws_base || !feat) return MMSA_ERR_ARG;
+  const mmsa_resnet_cfg& c = *cp;
+  const ResLayout L = res_layout(c);
+  ResWs ws = res_ws(c, L, ws_base);
+  hipStream_t st = (hipStream_t)stream;
+  ResCtx r{c, Eng{c.dtype, st, ws.splitk, ws.splitk_bytes, ws.colws}, w32, wt, bnbuf, nullptr, 0, (size_t)(c.dtype == MMSA_BF16 ? 2 : 4)};
+  const int B = c.batch;
+  // stem: im2col (reads the NCHW fp32 image) + GEMM against the zero-padded weight copy
+  const ConvDef& s = L.stem;
+  const int M0 = B * s.Hout * s.Wout;
+  RET_IF(stem_im2col(c.dtype, image, ws.col, B, 3, c.height, c.width, s.Hout, s.Wout, 7, 7, 2, 3, L.Kstem_pad, st));
+  RET_IF(pad_rows(c.dtype, w32 + s.w, ws.stem_w, 64, 147, L.Kstem_pad, st));
+  RET_IF(r.e.linear_fwd(ws.col, L.Kstem_pad, ws.stem_w, nullptr, ws.stem.z, 64, M0, 64, L.Kstem_pad));
+  RET_IF(bn_fwd(r, s, ws.stem, nullptr, ws.stem.y, MMSA_ACT_RELU, ws.bnws));
+  RET_IF(maxpool_fwd(c.dtype, ws.stem.y, ws.pool, ws.pool_idx, B, s.Hout, s.Wout, 64, st));
+  const void* x = ws.pool;
+  for (size_t i = 0; i < L.blocks.size(); ++i) {
+    const BlockDef& bd = L.blocks[i];
+    BlockWs& bw = ws.blocks[i];
+    RET_IF(conv_fwd(r, bd.c1, x, bw.c1.z));
+    RET_IF(bn_fwd(r, bd.c1, bw.c1, nullptr, bw.c1.y, MMSA_ACT_RELU, ws.bnws));
+    RET_IF(conv_fwd(r, bd.c2, bw.c1.y, bw.c2.z));
+    RET_IF(bn_fwd(r, bd.c2, bw.c2, nullptr, bw.c2.y, MMSA_ACT_RELU, ws.bnws));
+    RET_IF(conv_fwd(r, bd.c3, bw.c2.y, bw.c3.z));
+    const void* idn = x;
+    if (bd.has_ds) {
+      RET_IF(conv_fwd(r, bd.ds, x, bw.ds.z));
+      RET_IF(bn_fwd(r, bd.ds, bw.ds, nullptr, bw.ds.y, MMSA_ACT_NONE, ws.bnws));
+      idn = bw.ds.y;
+    }
+    RET_IF(bn_fwd(r, bd.c3, bw.c3, idn, bw.c3.y, MMSA_ACT_RELU, ws.bnws));
+    x = bw.c3.y;
+  }
+  RET_IF(avgpool_fwd(c.dtype, x, ws.pooled, B, L.Hf * L.Wf, L.feat_c, st));
+  RET_IF(r.e.linear_fwd(ws.pooled, L.feat_c, r.W(L.wproj), r.P(L.bproj), feat, c.out_dim, B, c.out_dim, L.feat_c,
+                        MMSA_ACT_NONE, nullptr, nullptr, 0, 1));
+  return MMSA_OK;
+}
+
+int mmsa_resnet_bwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt, void* ws_base, const float* dfeat, float* grad,
+                    int32_t accumulate, void* stream) {
+  if (!cp || !res_cfg_ok(*cp) || !w32 || !wt || !ws_base || !dfeat || !grad) return MMSA_ERR_ARG;
+  const mmsa_resnet_cfg& c = *cp;
+  const ResLayout L = res_layout(c);
+  ResWs ws = res_ws(c, L, ws_base);
+  hipStream_t st = (hipStream_t)stream;
+  ResCtx r{c, Eng{c.dtype, st, ws.splitk, ws.splitk_bytes, ws.colws}, w32, wt, nullptr, grad, accumulate ? 1 : 0,
+           (size_t)(c.dtype == MMSA_BF16 ? 2 : 4)};
+  const int B = c.batch, D = c.out_dim, acc = r.acc;
+  // projection
+  RET_IF(cast_f32(c.dtype, dfeat, ws.dfeat_t, (long)B * D, st));
+  RET_IF(r.e.bias_grad(ws.dfeat_t, D, r.G(L.bproj), B, D, acc));
+  RET_IF(r.e.linear_wgrad(ws.dfeat_t, D, ws.pooled, L.feat_c, r.G(L.wproj), B, D, L.feat_c, acc));
+  RET_IF(r.e.linear_dgrad(ws.dfeat_t, D, r.W(L.wproj), ws.dpooled, L.feat_c, B, D, L.feat_c));
+  void *dOut = ws.g0, *t1 = ws.g1, *t2 = ws.g2, *t3 = ws.g3;
+  RET_IF(avgpool_bwd(c.dtype, ws.dpooled, dOut, B, L.Hf * L.Wf, L.feat_c, st));
+  for (int i = (int)L.blocks.size() - 1; i >= 0; --i) {
+    const BlockDef& bd = L.blocks[i];
+    BlockWs& bw = ws.blocks[i];
+    const void* xin = i == 0 ? ws.pool : ws.blocks[i - 1].c3.y;
+    // out = relu(bn3(z3) + idn): dz3 -> t1, masked gradient of the identity branch -> t2
+    RET_IF(bn_bwd(r, bd.c3, bw.c3, dOut, bw.c3.y, t1, t2, MMSA_ACT_RELU, ws.bnws));
+    RET_IF(conv_wgrad(r, bd.c3, t1, bw.c2.y, r.G(bd.c3.w), acc));
+    RET_IF(conv_dgrad(r, bd.c3, t1, t3, nullptr));                                   // dy2 -> t3
+    RET_IF(bn_bwd(r, bd.c2, bw.c2, t3, bw.c2.y, t1, nullptr, MMSA_ACT_RELU, ws.bnws));  // dz2 -> t1
+    RET_IF(conv_wgrad(r, bd.c2, t1, bw.c1.y, r.G(bd.c2.w), acc));
+    RET_IF(conv_dgrad(r, bd.c2, t1, t3, nullptr));                                   // dy1 -> t3
+    RET_IF(bn_bwd(r, bd.c1, bw.c1, t3, bw.c1.y, t1, nullptr, MMSA_ACT_RELU, ws.bnws));  // dz1 -> t1
+    if (const char* dbg = getenv("MMSA_RESNET_BWD_STOP_BLOCK")) {  // diagnostic: leave t3 = dy1, t1 = dz1 of block i intact
+      if (atoi(dbg) == i) return MMSA_OK;
+    }
+    RET_IF(conv_wgrad(r, bd.c1, t1, xin, r.G(bd.c1.w), acc));
+    const void* skip = t2;  // identity block: the skip gradient is added to conv1's data gradient
+    if (bd.has_ds) {
+      RET_IF(bn_bwd(r, bd.ds, bw.ds, t2, nullptr, t3, nullptr, MMSA_ACT_NONE, ws.bnws));  // dzd -> t3
+      RET_IF(conv_wgrad(r, bd.ds, t3, xin, r.G(bd.ds.w), acc));
+      RET_IF(conv_dgrad(r, bd.ds, t3, dOut, nullptr));  // dOut is free: holds the projected-skip data gradient
+      skip = dOut;
+      RET_IF(conv_dgrad(r, bd.c1, t1, t2, skip));       // dx -> t2
+      void* t = dOut; dOut = t2; t2 = t;
+    } else {
+      RET_IF(conv_dgrad(r, bd.c1, t1, dOut, skip));     // dx -> dOut (its old content was consumed by bn3's backward)
+    }
+  }
+  // max-pool, stem BN + ReLU, stem conv (weight gradient only: the image needs none)
+  const ConvDef& s = L.stem;
+  RET_IF(maxpool_bwd(c.dtype, dOut, ws.pool_idx, t1, B, s.Hout, s.Wout, 64, st));
+  RET_IF(bn_bwd(r, s, ws.stem, t1, ws.stem.y, t2, nullptr, MMSA_ACT_RELU, ws.bnws));
+  const int M0 = B * s.Hout * s.Wout;
+  {
+    GemmParams p = Eng::blank();
+    p.A = t2; p.lda = 64; p.a_kmajor = 1; p.B = ws.col; p.ldb = L.Kstem_pad; p.b_kmajor = 1; p.C = ws.stem_dw;
+    p.ldc = L.Kstem_pad; p.M = 64; p.N = L.Kstem_pad; p.K = M0; p.out_f32 = 1;
+    p.split_k = r.e.pick_split(64, L.Kstem_pad, M0);
+    p.ws = ws.splitk;
+    RET_IF(r.e.gemm(p));
+  }
+  RET_IF(unpad_rows(ws.stem_dw, r.G(s.w), 64, L.Kstem_pad, 147, acc, st));
+  return MMSA_OK;
+}
+
+}  // extern "C"

@@ -202,8 +202,25 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 #define COLSUM_CHUNKS 128
 size_t colsum_ws_bytes(int N) { return (size_t)COLSUM_CHUNKS * N * sizeof(float); }
 
+// small / unaligned widths (the 3-class logits): one thread per column, fixed order
+template <typename T>
+__global__ void colsum_small_kernel(const T* __restrict__ x, long ldx, float* __restrict__ out, int accumulate, int M, int N) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float a = 0.f;
+  for (int r = 0; r < M; ++r) a += to_f32<T>(x[(long)r * ldx + c]);
+  out[c] = accumulate ? out[c] + a : a;
+}
+
 int colsum(int dtype, const void* x, long ldx, float* out, int accumulate, float* ws, int M, int N, hipStream_t st) {
-  if (N % 4 || ldx % 4) return MMSA_ERR_ARG;
+  if (N % 4 || ldx % 4) {
+    if (dtype == MMSA_BF16)
+      hipLaunchKernelGGL(colsum_small_kernel<bf16>, dim3(cdiv(N, 64)), dim3(64), 0, st, (const bf16*)x, ldx, out, accumulate, M, N);
+    else
+      hipLaunchKernelGGL(colsum_small_kernel<float>, dim3(cdiv(N, 64)), dim3(64), 0, st, (const float*)x, ldx, out, accumulate, M, N);
+    MMSA_CHECK_LAUNCH();
+    return MMSA_OK;
+  }
   const int rpc = cdiv(M, COLSUM_CHUNKS);
   const int chunks = cdiv(M, rpc);
   dim3 grid(chunks, cdiv(N, 1024));
@@ -308,4 +325,26 @@ int embed_backward(int dtype, const long long* ids, const void* de, float* dword
   MMSA_CHECK_LAUNCH();
   // token-type row 0 receives every token's gradient (default token_type_ids = 0); row 1 gets none
   return colsum(dtype, de, H, dtype0, accumulate, ws, M, H, st);
+}
+
+// ------------------------------------------------------------------------------------------------ tanh backward
+// dx = dy * (1 - y^2)  (BERT pooler)
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                       long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 d = Vec4<T>::load(dy + i * 4), v = Vec4<T>::load(y + i * 4);
+    Vec4<T>::store(dx + i * 4, d * (1.0f - v * v));
+  }
+}
+int tanh_bwd(int dtype, const void* dy, const void* y, void* dx, long n, hipStream_t st) {
+  if (n % 4) return MMSA_ERR_ARG;
+  const int grid = (int)min((n / 4 + 255) / 256, 2048L);
+  if (dtype == MMSA_BF16)
+    hipLaunchKernelGGL(tanh_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)y, (bf16*)dx, n / 4);
+  else
+    hipLaunchKernelGGL(tanh_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dx,
+                       n / 4);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
 }

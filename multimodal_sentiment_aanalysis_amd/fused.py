@@ -1,0 +1,120 @@
+"""Fused training step on the flat buffers: the body of the reference's `Trainer.train_epoch` loop
+(Trainer.py:59-81: zero_grad -> forward -> CE -> backward -> clip_grad_norm_(1.0) -> AdamW.step) with
+
+  * CE forward + dlogits in one kernel (mmsa_ce_fwd_bwd), backward entered with that gradient,
+  * gradients written once into the flat fp32 buffer by the engines (overwrite mode: no zero_grad pass),
+  * data-parallel: per-engine gradient ranges all-reduced (RCCL = torch.distributed "nccl") on a side HIP stream as
+    soon as that engine's backward kernels are enqueued, overlapping with the remaining backward,
+  * global-norm clip + AdamW + bf16 working-copy refresh as two kernels over the flat buffers
+    (mmsa_grad_norm, mmsa_adamw_step), the 1/world_size average folded into their grad_scale.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+from .engine import HeadEngine, engines_of, materialize
+
+
+class GradReducer:
+    """Bucketed SUM all-reduce of contiguous gradient ranges. On GPU the collectives run on a side stream ordered
+    after an event recorded when the range's producer kernels were enqueued; `finish()` makes the current stream wait.
+    Works on CPU tensors with the gloo backend too (used by the world_size-2 CPU tests)."""
+
+    def __init__(self, flat_g, bucket_bytes=64 << 20, group=None):
+        self.flat_g, self.group = flat_g, group
+        self.bucket_elems = max(1, bucket_bytes // flat_g.element_size())
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.works = []
+        self.stream = torch.cuda.Stream(device=flat_g.device) if flat_g.is_cuda else None
+
+    def buckets(self, start, length):
+        out, a, end = [], start, start + length
+        while a < end:
+            b = min(end, a + self.bucket_elems)
+            out.append((a, b))
+            a = b
+        return out
+
+    def reduce_range(self, start, length):
+        if self.world == 1 or length <= 0:
+            return
+        if self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat_g.device))
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                for a, b in self.buckets(start, length):
+                    self.works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                                      async_op=True))
+        else:
+            for a, b in self.buckets(start, length):
+                self.works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                                  async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.stream is not None:
+            torch.cuda.current_stream(self.flat_g.device).wait_stream(self.stream)
+
+
+class FusedTrainStep:
+    """model: MultimodalTransformerModel (Trainer contract). One call = one optimizer step."""
+
+    def __init__(self, model, device, precision="bf16", lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
+                 max_norm=1.0, bucket_bytes=64 << 20):
+        self.model, self.device = model, torch.device(device)
+        self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.state = materialize(model, self.device, precision)
+        n = self.state.flat_w.numel()
+        self.m = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.v = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.t = 0
+        L = _lib.load()
+        self.norm_ws = torch.empty(L.mmsa_grad_norm_ws_bytes(), dtype=torch.uint8, device=self.device)
+        self.norm_out = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.reducer = GradReducer(self.state.flat_g, bucket_bytes) if self.world > 1 else None
+        if self.world > 1:  # identical replicas: parameters and BN buffers from rank 0
+            dist.broadcast(self.state.flat_w, 0)
+            dist.broadcast(self.state.flat_bn, 0)
+        self._ranges = {id(e): (off, n) for e, off, n in self.state.ranges}
+        for e, off, n in self.state.ranges:
+            e._grad_ready_hook = self._on_grads_ready if self.reducer is not None else None
+
+    def _on_grads_ready(self, eng):
+        off, n = self._ranges[id(eng)]
+        self.reducer.reduce_range(off, n)
+
+    def step(self, image, token_ids, attention_mask, labels):
+        if not self.state.valid():
+            raise _lib.MmsaError("flat parameter buffers were invalidated (model.to()/.float() after FusedTrainStep)")
+        L = _lib.load()
+        model = self.model
+        model.train()
+        for e, _, _ in self.state.ranges:
+            e._overwrite_next = True  # every gradient range is written (not accumulated) by this backward
+        logits, _aux = model(image, token_ids, attention_mask, labels)
+        B, C = logits.shape
+        dlogits = torch.empty_like(logits)
+        check(L.mmsa_ce_fwd_bwd(ptr(logits), ptr(labels), ptr(self.loss), ptr(dlogits), None, B, C, 1.0, stream_ptr()),
+              "mmsa_ce_fwd_bwd")
+        logits.backward(dlogits)
+        if self.reducer is not None:
+            self.reducer.finish()
+        scale = 1.0 / self.world
+        st = self.state
+        n = st.flat_w.numel()
+        check(L.mmsa_grad_norm(ptr(st.flat_g), n, scale, self.max_norm, ptr(self.norm_out), ptr(self.norm_ws), stream_ptr()),
+              "mmsa_grad_norm")
+        self.t += 1
+        check(L.mmsa_adamw_step(ptr(st.flat_w), ptr(st.flat_g), ptr(self.m), ptr(self.v), ptr(st.flat_wt), n, self.lr,
+                                self.betas[0], self.betas[1], self.eps, self.wd, self.t, ptr(self.norm_out), scale,
+                                stream_ptr()), "mmsa_adamw_step")
+        for e, _, _ in st.ranges:
+            if not isinstance(e, HeadEngine):
+                e.mark_weights_fresh()
+        return self.loss, logits

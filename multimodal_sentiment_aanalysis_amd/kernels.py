@@ -122,3 +122,46 @@ def attention_bwd(qkv, mask, dctx, B, S, heads, impl=None):
     check(L.mmsa_attention_bwd(impl, ptr(qkv), ptr(mask), ptr(dctx), ptr(dqkv), ptr(ws), B, S, heads, 64,
                                stream_ptr()), "mmsa_attention_bwd")
     return dqkv
+
+
+def bn_fwd(x, gamma, beta, running_mean, running_var, res=None, act=ACT_NONE, training=True, eps=1e-5, momentum=0.1):
+    L = _lib.load()
+    M, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(L.mmsa_bn_ws_bytes(C), x.device, "bn")
+    check(L.mmsa_bn_fwd(dtype_code(x), ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(mean),
+                        ptr(invstd), ptr(res), ptr(y), ptr(ws), M, C, eps, momentum, act, int(training), stream_ptr()),
+          "mmsa_bn_fwd")
+    return y, mean, invstd
+
+
+def bn_bwd(dy, x, y, mean, invstd, gamma, beta, act=ACT_NONE, training=True, want_dres=False):
+    L = _lib.load()
+    M, C = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(L.mmsa_bn_ws_bytes(C), x.device, "bn")
+    check(L.mmsa_bn_bwd(dtype_code(x), ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(dx),
+                        ptr(dres), ptr(dgamma), ptr(dbeta), 0, ptr(ws), M, C, act, int(training), stream_ptr()),
+          "mmsa_bn_bwd")
+    return dx, dres, dgamma, dbeta
+
+
+def maxpool_fwd(x, B, H, W, C):
+    L = _lib.load()
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty(B * OH * OW, C, dtype=x.dtype, device=x.device)
+    idx = torch.empty(B * OH * OW, C, dtype=torch.uint8, device=x.device)
+    check(L.mmsa_maxpool_fwd(dtype_code(x), ptr(x), ptr(y), ptr(idx), B, H, W, C, stream_ptr()), "mmsa_maxpool_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, B, H, W, C):
+    L = _lib.load()
+    dx = torch.empty(B * H * W, C, dtype=dy.dtype, device=dy.device)
+    check(L.mmsa_maxpool_bwd(dtype_code(dy), ptr(dy), ptr(idx), ptr(dx), B, H, W, C, stream_ptr()), "mmsa_maxpool_bwd")
+    return dx

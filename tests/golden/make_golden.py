@@ -1,0 +1,269 @@
+"""Generates the golden fixtures under tests/golden/ (run in the BUILD container only; needs /root/reference and,
+for the BERT fixtures, the `transformers` package):
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tests/golden/make_golden.py
+
+Fixtures hold plain arrays only (inputs, weights, expected outputs / gradients): no pickled modules, no reference
+source. The reference classes are imported from /root/reference/MML_ZYC and CALLED to produce the expected values;
+their encoder slots (eeg_net / eye_net / pps_net) are replaced by nn.Identity so that the real fusion code paths
+(MultimodalModel.py:287-313 and :388-404) run on given 256-d feature vectors.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/MML_ZYC")
+sys.dont_write_bytecode = True
+
+import MultimodalModel as REF  # noqa: E402  (the reference's file)
+
+
+def npz(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        out[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB, {len(out)} arrays")
+
+
+def sd_arrays(module, prefix="w."):
+    return {prefix + k: v for k, v in module.state_dict().items()}
+
+
+def grads(module, prefix="g."):
+    return {prefix + n: p.grad for n, p in module.named_parameters() if p.grad is not None}
+
+
+def no_dropout(module):
+    for m in module.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+
+
+def rnd(*shape, seed):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+# ------------------------------------------------------------------------------------------------ A1
+def gen_cross_modal():
+    torch.manual_seed(0)
+    m = REF.CrossModalTransformer()
+    with torch.no_grad():  # make zero-initialised biases / unit norms non-trivial
+        m.multihead_attn.in_proj_bias.normal_(0, 0.1)
+        m.multihead_attn.out_proj.bias.normal_(0, 0.1)
+        m.norm.weight.add_(0.1 * torch.randn(256))
+        m.norm.bias.add_(0.1 * torch.randn(256))
+    for tag, Lk in (("l1", 1), ("l4", 4)):
+        B = 16
+        q = rnd(B, 256, seed=1).requires_grad_(True)
+        k = (rnd(B, 256, seed=2) if Lk == 1 else rnd(B, Lk, 256, seed=2)).requires_grad_(True)
+        v = (rnd(B, 256, seed=3) if Lk == 1 else rnd(B, Lk, 256, seed=3)).requires_grad_(True)
+        w = rnd(B, 256, seed=4)
+        m.zero_grad()
+        out = m(q, k, v)
+        (out * w).sum().backward()
+        npz(f"a1_cross_modal_{tag}.npz", q=q, k=k, v=v, wgt=w, out=out, dq=q.grad, dk=k.grad, dv=v.grad,
+            **sd_arrays(m), **grads(m))
+
+
+# ------------------------------------------------------------------------------------------------ A2
+def gen_mm_fusion():
+    torch.manual_seed(1)
+    m = REF.MultiModalEncoder()
+    m.eeg_net, m.eye_net, m.pps_net = nn.Identity(), nn.Identity(), nn.Identity()
+    with torch.no_grad():
+        m.multihead_attn.in_proj_bias.normal_(0, 0.1)
+        m.fusion_mlp[2].weight.add_(0.1 * torch.randn(256))
+        m.fusion_mlp[2].bias.add_(0.1 * torch.randn(256))
+    B = 16
+    feats = [(3.0 * rnd(B, 256, seed=10 + i)).requires_grad_(True) for i in range(3)]
+    w = rnd(B, 256, seed=20)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    arrays = {"w." + k: v for k, v in sd0.items()}
+    for mode in ("train", "eval"):
+        m.load_state_dict(sd0)
+        m.train(mode == "train")
+        m.zero_grad()
+        for f in feats:
+            f.grad = None
+        out = m(*feats)
+        (out * w).sum().backward()
+        arrays.update({f"{mode}.out": out, **{f"{mode}.df{i}": feats[i].grad for i in range(3)}})
+        arrays.update({f"{mode}.g.{n}": p.grad for n, p in m.named_parameters() if p.grad is not None})
+        if mode == "train":
+            arrays.update({"train.post." + k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    # mean-pool twin (ME-MHACL/model.py:69-73) through the same reference attention module
+    m.load_state_dict(sd0)
+    m.eval()
+    seq = torch.stack([torch.nn.functional.normalize(f.detach(), dim=-1) for f in feats], dim=0)
+    attn, _ = m.multihead_attn(seq, seq, seq)
+    arrays["eval.mean_pool_out"] = m.fusion_mlp(attn.mean(dim=0))
+    npz("a2_mm_fusion.npz", wgt=w, **{f"f{i}": feats[i] for i in range(3)}, **arrays)
+
+
+# ------------------------------------------------------------------------------------------------ A1 + A4 composed
+def ref_head_model(seed):
+    torch.manual_seed(seed)
+    m = REF.MultimodalTransformerModel()
+    m.eeg_net, m.eye_net, m.pps_net = nn.Identity(), nn.Identity(), nn.Identity()
+    no_dropout(m)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, (nn.BatchNorm1d, nn.LayerNorm)):
+                mod.weight.add_(0.1 * torch.randn_like(mod.weight))
+                mod.bias.add_(0.1 * torch.randn_like(mod.bias))
+    return m
+
+
+def gen_fusion_head():
+    m = ref_head_model(2)
+    B = 16
+    feats = [rnd(B, 256, seed=30 + i).requires_grad_(True) for i in range(3)]
+    wa, wv = rnd(B, 3, seed=40), rnd(B, 3, seed=41)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    arrays = {"w." + k: v for k, v in sd0.items()}
+    for mode in ("train", "eval"):
+        m.load_state_dict(sd0)
+        m.train(mode == "train")
+        m.zero_grad()
+        for f in feats:
+            f.grad = None
+        arousal, valence = m(*feats)  # labels=None -> (arousal, valence), MultimodalModel.py:319-320
+        ((arousal * wa).sum() + (valence * wv).sum()).backward()
+        arrays.update({f"{mode}.arousal": arousal, f"{mode}.valence": valence,
+                       **{f"{mode}.df{i}": feats[i].grad for i in range(3)}})
+        arrays.update({f"{mode}.g.{n}": p.grad for n, p in m.named_parameters() if p.grad is not None})
+        if mode == "train":
+            arrays.update({"train.post." + k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    npz("a4_fusion_head.npz", wa=wa, wv=wv, **{f"f{i}": feats[i] for i in range(3)}, **arrays)
+
+
+# ------------------------------------------------------------------------------------------------ A5, A6
+def gen_small_heads():
+    torch.manual_seed(3)
+    c = REF.Classifier()
+    p = REF.ProjectionHead()
+    no_dropout(c)
+    no_dropout(p)
+    B = 16
+    x = rnd(B, 256, seed=50).requires_grad_(True)
+    wa, wv, wz = rnd(B, 3, seed=51), rnd(B, 3, seed=52), rnd(B, 128, seed=53)
+    c.train()
+    a, v = c(x)
+    ((a * wa).sum() + (v * wv).sum()).backward()
+    arr = dict(x=x, wa=wa, wv=wv, wz=wz, cls_a=a, cls_v=v, cls_dx=x.grad.clone())
+    arr.update({"cls.w." + k: t for k, t in c.state_dict().items()})
+    arr.update({"cls.g." + n: t.grad for n, t in c.named_parameters()})
+    x.grad = None
+    sd0 = {k: t.clone() for k, t in p.state_dict().items()}
+    arr.update({"proj.w." + k: t for k, t in sd0.items()})
+    p.train()
+    z = p(x)
+    (z * wz).sum().backward()
+    arr.update(proj_z=z, proj_dx=x.grad.clone())
+    arr.update({"proj.g." + n: t.grad for n, t in p.named_parameters()})
+    arr.update({"proj.post." + k: t.clone() for k, t in p.state_dict().items() if "running" in k})
+    # A6: CrossEntropyLoss (Trainer.py:17,68)
+    logits = rnd(B, 3, seed=60).requires_grad_(True)
+    labels = torch.randint(0, 3, (B,), generator=torch.Generator().manual_seed(61))
+    loss = nn.CrossEntropyLoss()(logits, labels)
+    loss.backward()
+    arr.update(ce_logits=logits, ce_labels=labels, ce_loss=loss, ce_dlogits=logits.grad)
+    npz("a5_a6_heads_ce.npz", **arr)
+
+
+# ------------------------------------------------------------------------------------------------ A7
+def gen_train_step():
+    """Two Trainer.train_epoch bodies (Trainer.py:59-81): zero_grad, forward, CE, backward, clip_grad_norm_(1.0),
+    AdamW(lr 1e-4, weight_decay 0.01).step(), on the reference fusion head fed with fixed feature vectors
+    (the older single-head contract: only the arousal logits enter the loss)."""
+    m = ref_head_model(4)
+    m.train()
+    B = 16
+    feats = [rnd(B, 256, seed=70 + i) for i in range(3)]
+    labels = torch.randint(0, 3, (B,), generator=torch.Generator().manual_seed(73))
+    arrays = {"w0." + k: v.clone() for k, v in m.state_dict().items()}
+    params = [p for n, p in m.named_parameters()]
+    opt = torch.optim.AdamW(params, lr=0.0001, weight_decay=0.01)
+    crit = nn.CrossEntropyLoss()
+    for step in (1, 2):
+        opt.zero_grad()
+        arousal, _ = m(*feats)
+        loss = crit(arousal, labels)
+        loss.backward()
+        total = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        arrays[f"loss{step}"] = loss.detach()
+        arrays[f"norm{step}"] = total
+        arrays.update({f"w{step}." + k: v.clone() for k, v in m.state_dict().items()})
+    npz("a7_train_step.npz", labels=labels, **{f"f{i}": feats[i] for i in range(3)}, **arrays)
+
+
+# ------------------------------------------------------------------------------------------------ E1 (not in reference)
+def gen_bert():
+    from transformers import BertConfig, BertModel
+    import multimodal_sentiment_aanalysis_amd as mm
+    from multimodal_sentiment_aanalysis_amd.engine import BERT_BASE, BertTextNet
+    mini = dict(hidden=128, layers=2, heads=2, intermediate=512, vocab=1000, max_pos=64, type_vocab=2, ln_eps=1e-12)
+
+    def hf_model(cfg):
+        c = BertConfig(vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"],
+                       num_attention_heads=cfg["heads"], intermediate_size=cfg["intermediate"],
+                       max_position_embeddings=cfg["max_pos"], type_vocab_size=cfg["type_vocab"],
+                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=cfg["ln_eps"])
+        return BertModel(c).eval()
+
+    # mini config with stored weights (HF initialisation, masked and unmasked)
+    torch.manual_seed(5)
+    hf = hf_model(mini)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if n.endswith("bias") or "LayerNorm" in n:
+                p.add_(0.05 * torch.randn_like(p))
+    ids = torch.randint(0, mini["vocab"], (4, 32), generator=torch.Generator().manual_seed(6))
+    mask = torch.ones(4, 32, dtype=torch.long)
+    mask[1, 20:] = 0
+    mask[3, 7:] = 0
+    with torch.no_grad():
+        o1 = hf(input_ids=ids)
+        o2 = hf(input_ids=ids, attention_mask=mask)
+    npz("e1_bert_mini.npz", ids=ids, mask=mask, hidden_nomask=o1.last_hidden_state, pooled_nomask=o1.pooler_output,
+        hidden_mask=o2.last_hidden_state, pooled_mask=o2.pooler_output,
+        **{"w." + k: v for k, v in hf.state_dict().items() if "position_ids" not in k})
+
+    # BERT-base: weights regenerated from a seed by the product's initialiser on both sides; only outputs stored
+    torch.manual_seed(1234)
+    net = BertTextNet(BERT_BASE)
+    sd = {k[len("bert."):]: v for k, v in net.state_dict().items() if k.startswith("bert.")}
+    hfb = hf_model(BERT_BASE)
+    missing = hfb.load_state_dict(sd, strict=False)
+    assert not [k for k in missing.missing_keys if "position_ids" not in k], missing
+    ids = torch.randint(0, BERT_BASE["vocab"], (16, 128), generator=torch.Generator().manual_seed(7))
+    ids[:, 0] = 101
+    with torch.no_grad():
+        ob = hfb(input_ids=ids)
+    npz("e1_bert_base_seed1234.npz", ids=ids, pooled=ob.pooler_output, hidden_cls=ob.last_hidden_state[:, 0],
+        hidden_row5=ob.last_hidden_state[5])
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["a1", "a2", "a4", "a5", "a7", "e1"]
+    if "a1" in which:
+        gen_cross_modal()
+    if "a2" in which:
+        gen_mm_fusion()
+    if "a4" in which:
+        gen_fusion_head()
+    if "a5" in which:
+        gen_small_heads()
+    if "a7" in which:
+        gen_train_step()
+    if "e1" in which:
+        gen_bert()

@@ -119,6 +119,10 @@ CONVS = [  # B, H, W, Cin, Cout, k, stride, pad
     (3, 8, 8, 128, 64, 1, 1, 0),
     (2, 8, 8, 64, 128, 1, 2, 0),
     (2, 14, 14, 128, 128, 3, 1, 1),
+    (2, 16, 16, 64, 64, 3, 2, 1),
+    (2, 8, 8, 128, 128, 3, 2, 1),
+    (2, 16, 16, 256, 256, 1, 2, 0),
+    (2, 16, 16, 256, 64, 1, 1, 0),
 ]
 
 
@@ -218,3 +222,52 @@ def test_attention(dev, impl, dtype, B, S, heads, masked):
     scale = dqkv_ref.abs().max().item()
     err = (got - dqkv_ref).abs().max().item() / scale
     assert err < (3e-2 if dtype == torch.bfloat16 else 1e-4), f"attn bwd err {err}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C,act,use_res", [(512, 64, ACT_RELU, False), (128, 64, ACT_RELU, True), (2048, 256, ACT_RELU, True),
+                                             (32, 512, ACT_NONE, False), (8, 128, ACT_RELU, False), (16, 256, ACT_GELU, False),
+                                             (1000, 192, ACT_RELU, True)])
+def test_batchnorm(dev, dtype, M, C, act, use_res):
+    x = rnd((M, C), dtype, dev, 1, 2.0)
+    res = rnd((M, C), dtype, dev, 2) if use_res else None
+    gamma = (1 + 0.1 * rnd((C,), torch.float32, dev, 3))
+    beta = 0.1 * rnd((C,), torch.float32, dev, 4)
+    dy = rnd((M, C), dtype, dev, 5)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    xr = x.cpu().double().requires_grad_(True)
+    rr = res.cpu().double().requires_grad_(True) if use_res else None
+    gr, br = gamma.cpu().double().requires_grad_(True), beta.cpu().double().requires_grad_(True)
+    rmr, rvr = torch.zeros(C, dtype=torch.double), torch.ones(C, dtype=torch.double)
+    z = F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)
+    if use_res:
+        z = z + rr
+    yr = torch.relu(z) if act == ACT_RELU else (F.gelu(z) if act == ACT_GELU else z)
+    yr.backward(dy.cpu().double())
+    y, mean, invstd = K.bn_fwd(x, gamma, beta, rm, rv, res, act, True)
+    assert_close(y, yr.detach(), dtype, "bn fwd")
+    assert_close(rm, rmr, torch.float32, "running mean")
+    assert_close(rv, rvr, torch.float32, "running var")
+    dx, dres, dg, db = K.bn_bwd(dy, x, y, mean, invstd, gamma, beta, act, True, want_dres=use_res)
+    assert_close(dx, xr.grad, dtype, "bn dx")
+    assert_close(dg, gr.grad, torch.float32 if dtype == torch.float32 else torch.bfloat16, "bn dgamma")
+    assert_close(db, br.grad, torch.float32 if dtype == torch.float32 else torch.bfloat16, "bn dbeta")
+    if use_res:
+        assert_close(dres, rr.grad, dtype, "bn dres")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [(2, 32, 32, 64), (1, 9, 7, 64), (3, 16, 16, 128)])
+def test_maxpool(dev, dtype, B, H, W, C):
+    x = torch.relu(rnd((B, H, W, C), dtype, dev, 1))  # many exact ties at 0, like the post-ReLU stem output
+    xr = x.cpu().double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    OH, OW = yr.shape[2], yr.shape[3]
+    dy = rnd((B, OH, OW, C), dtype, dev, 2)
+    yr.backward(dy.cpu().double().permute(0, 3, 1, 2))
+    y, idx = K.maxpool_fwd(x.view(-1, C), B, H, W, C)
+    assert_close(y.view(B, OH, OW, C), yr.detach().permute(0, 2, 3, 1), dtype, "maxpool fwd")
+    dx = K.maxpool_bwd(dy.view(-1, C), idx, B, H, W, C)
+    # exact scatter in fp32; in bf16 the up-to-4 overlapping contributions are summed in fp32 and rounded once
+    tol = 1e-6 if dtype == torch.float32 else 3e-2
+    assert (dx.view(B, H, W, C).cpu().double() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() < tol
