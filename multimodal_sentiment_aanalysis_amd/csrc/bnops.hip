@@ -10,7 +10,7 @@
 #include "gemm_epilogue.h"
 #include "ops.h"
 
-#define BN_CHUNKS 256
+#define BN_CHUNKS 1024
 
 struct BnMap {
   int cthreads, rlanes, cgroups;  // column threads per block, row lanes per block, grid.y
@@ -54,16 +54,28 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restri
   }
 }
 
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int M, int C, float eps,
-                                         float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// finalize kernels: 256 threads = 16 columns x 16 partial-lanes (fixed summation tree, see partial_finalize_kernel)
+#define BN_FIN_COLS 16
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int M, int C,
+                                                                float eps, float momentum, float* __restrict__ mean,
+                                                                float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var) {
+  __shared__ double rs[16][17], rq[16][17];
+  const int cc = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = blockIdx.x * BN_FIN_COLS + cc;
   double s = 0, q = 0;
-  for (int b = 0; b < chunks; ++b) {
-    s += part[((long)b * 2 + 0) * C + c];
-    q += part[((long)b * 2 + 1) * C + c];
-  }
+  if (c < C)
+    for (int b = r; b < chunks; b += 16) {
+      s += part[((long)b * 2 + 0) * C + c];
+      q += part[((long)b * 2 + 1) * C + c];
+    }
+  rs[r][cc] = s;
+  rq[r][cc] = q;
+  __syncthreads();
+  if (r != 0 || c >= C) return;
+  s = 0; q = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { s += rs[k][cc]; q += rq[k][cc]; }
   const double mu = s / M;
   double var = q / M - mu * mu;
   if (var < 0) var = 0;
@@ -159,15 +171,25 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
 }
 
 // sums[0][C] = dbeta, sums[1][C] = dgamma (kept for pass 2) and (+)= into the parameter gradients
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ sums,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C,
+                                                              float* __restrict__ sums, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
+  __shared__ float rs[16][17], rq[16][17];
+  const int cc = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = blockIdx.x * BN_FIN_COLS + cc;
   float s = 0, q = 0;
-  for (int b = 0; b < chunks; ++b) {
-    s += part[((long)b * 2 + 0) * C + c];
-    q += part[((long)b * 2 + 1) * C + c];
-  }
+  if (c < C)
+    for (int b = r; b < chunks; b += 16) {
+      s += part[((long)b * 2 + 0) * C + c];
+      q += part[((long)b * 2 + 1) * C + c];
+    }
+  rs[r][cc] = s;
+  rq[r][cc] = q;
+  __syncthreads();
+  if (r != 0 || c >= C) return;
+  s = 0; q = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { s += rs[k][cc]; q += rq[k][cc]; }
   sums[c] = s;
   sums[C + c] = q;
   if (dgamma) {
@@ -219,7 +241,7 @@ static int bn_forward_t(const T* x, const float* gamma, const float* beta, float
     const int rpc = max(cdiv(M, BN_CHUNKS), m.rlanes);
     const int chunks = cdiv(M, rpc);
     hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(chunks, m.cgroups), dim3(256), 0, st, x, ws, M, C, m.cthreads, rpc);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)ws, chunks, M, C, eps,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, BN_FIN_COLS)), dim3(256), 0, st, (const float*)ws, chunks, M, C, eps,
                        momentum, mean, invstd, running_mean, running_var);
   } else {
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)running_mean,
@@ -254,7 +276,7 @@ static int bn_backward_t(const T* dy, const T* x, const T* y, const float* mean,
   float* sums = ws + (size_t)BN_CHUNKS * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(chunks, m.cgroups), dim3(256), 0, st, dy, x, y, mean, invstd, gamma,
                      beta, ws, M, C, m.cthreads, rpc, act);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)ws, chunks, C, sums,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, BN_FIN_COLS)), dim3(256), 0, st, (const float*)ws, chunks, C, sums,
                      dgamma, dbeta, accumulate);
   const int gx = (int)min((long)cdiv(M, m.rlanes), 2048L);
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(gx, m.cgroups), dim3(256), 0, st, dy, x, y, mean, invstd, gamma, beta,

@@ -10,7 +10,7 @@
 
 #define SBM 64
 #define SBN 64
-#define SBK 16
+#define SBK 32
 
 __device__ __forceinline__ long simt_tap_src(const ConvGeom& g, int pix, int ky, int kx) {
   const int ghw = g.GH * g.GW;
@@ -80,15 +80,26 @@ __global__ __launch_bounds__(256) void gemm_simt_kernel(GemmParams p) {
   for (int k0 = kbeg; k0 < kend; k0 += SBK) {
     // 64x16 elements per operand, 4 per thread. Pick the thread->element map so global reads are coalesced
     // along the contiguous dimension of each storage form.
+    float ta[SBK / 4], tb[SBK / 4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < SBK / 4; ++i) {  // issue all global loads of the step before any LDS write
       const int e = tid + 256 * i;
       int mm, kk;
-      if (p.a_kmajor) { mm = e & 63; kk = e >> 6; } else { kk = e & 15; mm = e >> 4; }
-      As[kk][mm] = simt_load_a<T>(p, m0 + mm, k0 + kk, kend);
+      if (p.a_kmajor) { mm = e & 63; kk = e >> 6; } else { kk = e & (SBK - 1); mm = e / SBK; }
+      ta[i] = simt_load_a<T>(p, m0 + mm, k0 + kk, kend);
       int nn, kb;
-      if (p.b_kmajor) { nn = e & 63; kb = e >> 6; } else { kb = e & 15; nn = e >> 4; }
-      Bs[kb][nn] = simt_load_b<T>(p, k0 + kb, n0 + nn, kend);
+      if (p.b_kmajor) { nn = e & 63; kb = e >> 6; } else { kb = e & (SBK - 1); nn = e / SBK; }
+      tb[i] = simt_load_b<T>(p, k0 + kb, n0 + nn, kend);
+    }
+#pragma unroll
+    for (int i = 0; i < SBK / 4; ++i) {
+      const int e = tid + 256 * i;
+      int mm, kk;
+      if (p.a_kmajor) { mm = e & 63; kk = e >> 6; } else { kk = e & (SBK - 1); mm = e / SBK; }
+      As[kk][mm] = ta[i];
+      int nn, kb;
+      if (p.b_kmajor) { nn = e & 63; kb = e >> 6; } else { kb = e & (SBK - 1); nn = e / SBK; }
+      Bs[kb][nn] = tb[i];
     }
     __syncthreads();
 #pragma unroll

@@ -126,19 +126,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 }
 
 // out[j] (+)= scale * sum_b part[b * stride + j]  for j in [0, n)   (fixed order: bitwise reproducible)
-__global__ void partial_finalize_kernel(const float* __restrict__ part, int nblk, long stride, int n,
-                                        float* __restrict__ out, int accumulate, float scale) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+// 256 threads = 16 columns x 16 partial-lanes: lane r sums partials r, r+16, ... (in order), then the 16 lane sums are
+// added in lane order — a fixed summation tree, so results are reproducible; 16x shorter serial chains than one
+// thread per column, and a wave reads 16 consecutive columns of 4 different partial rows (64-byte segments).
+__global__ __launch_bounds__(256) void partial_finalize_kernel(const float* __restrict__ part, int nblk, long stride, int n,
+                                                               float* __restrict__ out, int accumulate, float scale) {
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + c;
   float t = 0.f;
-  for (int b = 0; b < nblk; ++b) t += part[(long)b * stride + j];
-  t *= scale;
-  out[j] = accumulate ? out[j] + t : t;
+  if (j < n)
+    for (int b = r; b < nblk; b += 16) t += part[(long)b * stride + j];
+  red[r][c] = t;
+  __syncthreads();
+  if (r == 0 && j < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][c];
+    s *= scale;
+    out[j] = accumulate ? out[j] + s : s;
+  }
 }
 
 int partial_finalize(const float* part, int nblk, long stride, int n, float* out, int accumulate, float scale,
                      hipStream_t st) {
-  hipLaunchKernelGGL(partial_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, nblk, stride, n, out,
+  hipLaunchKernelGGL(partial_finalize_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, part, nblk, stride, n, out,
                      accumulate, scale);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;

@@ -82,7 +82,7 @@ def test_bert_engine(dev, precision, pol, tol_f, tol_g, B, S, masked):
     _check_grads(_grads(net), ref_g, tol_g, f"bert {precision}")
 
 
-@pytest.mark.parametrize("precision,pol,tol_f,tol_g", [("fp32", FP32, 5e-5, 1e-2), ("bf16", BF16, 3e-2, 2.5e-1)])
+@pytest.mark.parametrize("precision,pol,tol_f,tol_g", [("fp32", FP32, 5e-5, 1e-2), ("bf16", BF16, 3e-2, 5e-1)])
 @pytest.mark.parametrize("rcfg,B,HW", [(MINI_RESNET, 4, 96), (MINI_RESNET2, 3, 96), (MINI_RESNET, 2, 64)])
 def test_resnet_engine(dev, precision, pol, tol_f, tol_g, rcfg, B, HW):
     torch.manual_seed(0)
@@ -289,3 +289,58 @@ def test_full_model_bf16(dev):
     e_32 = (logits.cpu() - ref_32).abs().max().item()
     print(f"bf16 path: |dlogits| vs bf16-policy oracle {e_bf:.3e}, vs fp32 oracle {e_32:.3e}")
     assert e_bf < 3e-2
+
+
+def _run_engine_grads(make, run, env):
+    import os
+    old = os.environ.get("MMSA_BF16_SIMT")
+    os.environ["MMSA_BF16_SIMT"] = env
+    try:
+        torch.manual_seed(0)
+        net = make()
+        out = run(net)
+        torch.cuda.synchronize()
+        return out.detach().cpu(), _grads(net)
+    finally:
+        if old is None:
+            os.environ.pop("MMSA_BF16_SIMT", None)
+        else:
+            os.environ["MMSA_BF16_SIMT"] = old
+
+
+def test_bf16_mfma_engines_match_simt_engines(dev):
+    """The bf16 engines on the MFMA kernels vs the same engines forced onto the SIMT kernels (MMSA_BF16_SIMT=1): same
+    storage rounding, independent GEMM / attention code. This is the tight check of the bf16 backward; the oracle
+    comparison above is loose because the oracle does not round gradients to bf16 between layers."""
+    image, ids, mask, _ = synth_batch(4, 32, 96, 96, MINI_BERT["vocab"], seed=11)
+    wgt = torch.randn(4, 256, generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def make_r():
+        n = ResNetImageNet(MINI_RESNET)
+        n.precision = "bf16"
+        return n.to(dev).train()
+
+    def run_r(n):
+        o = n(image.to(dev))
+        (o * wgt).sum().backward()
+        return o
+
+    def make_b():
+        n = BertTextNet(MINI_BERT)
+        n.precision = "bf16"
+        return n.to(dev)
+
+    def run_b(n):
+        o = n(ids.to(dev), mask.to(dev))
+        (o * wgt).sum().backward()
+        return o
+
+    # ResNet tolerance: bf16 storage of activation gradients through train-mode BatchNorm is intrinsically noisy — the
+    # BN backward subtracts the batch mean of a gradient whose entries are nearly equal (the broadcast of the
+    # average-pool gradient), so a 2^-9 relative rounding of each entry becomes a 10-20 % relative change of the
+    # difference. Measured: MFMA vs SIMT engines 9-24 %, either vs the fp32 engine 17-39 % (DESIGN.md, "bf16 backward").
+    for nm, mk, rn, tol in (("resnet", make_r, run_r, 0.35), ("bert", make_b, run_b, 6e-2)):
+        o1, g1 = _run_engine_grads(mk, rn, "0")
+        o2, g2 = _run_engine_grads(mk, rn, "1")
+        assert rel_err(o1, o2) < 2e-2, f"{nm} forward MFMA vs SIMT {rel_err(o1, o2)}"
+        _check_grads(g1, g2, tol, f"{nm} bf16 MFMA vs SIMT", l2=True)
