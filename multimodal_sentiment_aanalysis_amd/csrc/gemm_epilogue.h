@@ -20,6 +20,31 @@ template <> struct Vec4<bf16> {
   }
 };
 
+// `bias4` = the 4 bias values of columns n..n+3 already in registers (zeros when there is no bias): the MFMA kernel
+// loads them once per column group instead of once per 16x16 tile.
+template <typename T>
+__device__ __forceinline__ void gemm_epilogue4b(const GemmParams& p, int m, int n, f32x4 v, f32x4 bias4) {
+  v += bias4;
+  if (p.C2) Vec4<T>::store((T*)p.C2 + (long)m * p.ldc2 + n, v);
+  if (p.act != MMSA_ACT_NONE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+  }
+  if (p.mul) {
+    f32x4 x = Vec4<T>::load((const T*)p.mul + (long)m * p.ldmul + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(x[r]);
+  }
+  if (p.add) v += Vec4<T>::load((const T*)p.add + (long)m * p.ldadd + n);
+  if (p.out_f32) {
+    float* c = (float*)p.C + (long)m * p.ldc + n;
+    if (p.accumulate) v += *(const f32x4*)c;
+    *(f32x4*)c = v;
+  } else {
+    Vec4<T>::store((T*)p.C + (long)m * p.ldc + n, v);
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n, f32x4 v) {
   if (p.bias) v += *(const f32x4*)(p.bias + n);

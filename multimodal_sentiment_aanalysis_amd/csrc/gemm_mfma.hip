@@ -1,8 +1,13 @@
 // bf16 MFMA GEMM for gfx950 (v_mfma_f32_16x16x32_bf16), fp32 accumulate.
 //
 // One 256-thread workgroup (4 waves, 2x2) computes a 128x128 tile of C; each wave owns 64x64 = 4x4 MFMA tiles.
-// K is consumed in steps of 64 through a double-buffered LDS image (2 x 32 KiB): the global loads of step t+1
-// are issued before the MFMAs of step t and written to the other LDS buffer after them (one barrier per step).
+// K is consumed in steps of 64 through a double-buffered LDS image (2 x 32 KiB). Staging is LDS-DMA:
+// `global_load_lds_dwordx4` (16 B per lane, 1 KiB per wave-instruction, no VGPR destination, no ds_write) for tile
+// t+1 is issued before the MFMAs of tile t; the barrier that ends the step waits for it (2-phase structure of the
+// CDNA4 guide, T3+T4 minimum form). The LDS image is lane-linear per wave-instruction, so the bank-conflict swizzle
+// is applied to the per-lane SOURCE address and, identically, to the fragment reads.
+// (GLDS = false keeps the register-staged variant: global_load_dwordx4 -> ds_write_b128, for A/B comparison;
+//  select with MMSA_GEMM_REGSTAGE=1.)
 //
 // Operands come in two storage forms (gemm.h): k-contiguous tiles are [128 rows][64 k] read with ds_read_b128
 // through a 16-byte XOR swizzle; k-major tiles are [64 k][128 cols] read with ds_read_b64_tr_b16 (the LDS
@@ -12,6 +17,8 @@
 //
 // Implicit-GEMM convolution gathers are resolved per 16-byte chunk at staging time: an invalid chunk (padding,
 // stride hole, row/col/k past the end) is redirected to a page of zeros, so the main loop is branch-free.
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include "gemm.h"
 #include "gemm_epilogue.h"
@@ -103,7 +110,10 @@ __device__ __forceinline__ long tap_src(const ConvGeom& g, const RowPix& r, int 
   return (((long)r.img * g.SH + sy) * g.SW + sx) * g.src_pix_stride;
 }
 
-template <bool A_KM, bool B_KM, int GATHER>
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <bool A_KM, bool B_KM, int GATHER, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,53 +144,71 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   const bf16* __restrict__ Bb = (const bf16*)p.B;
   const bf16* zp = (const bf16*)p.zero_page;
 
-  // ---- per-thread staging state (fixed over the K loop)
-  // k-contiguous tiles: chunk i -> row (tid>>3)+32i, 16-B chunk kc = tid&7
-  // k-major tiles     : chunk i -> k-row (tid>>4)+16i, 16-B chunk cc = tid&15
-  const int kc = tid & 7, rrow = tid >> 3;
-  const int cc = tid & 15, krow = tid >> 4;
-
-  long a_rowoff[4];  // !A_KM plain: element offset of the row (or -1)
-  RowPix a_pix[4];   // GATHER==1
-  long a_coloff = -1;  // A_KM: element offset of this thread's column chunk (or -1)
-  if constexpr (!A_KM) {
+  // ---- per-thread staging map (fixed over the K loop). Each thread moves 4 x 16 bytes per operand per K step.
+  // GLDS: wave-instruction `i` of wave w writes the 1-KiB LDS piece pi = 4w + i linearly (lane l -> byte 16 l):
+  //   k-contiguous tile: piece = 8 rows; lane -> row 8 pi + (l>>3), physical chunk l&7 = logical chunk ^ (row&7)
+  //   k-major tile     : piece = 4 k-rows; lane -> k-row 4 pi + (l>>4), physical chunk l&15 (32-byte XOR swizzle)
+  // register staging: k-contiguous chunk i -> row (tid>>3)+32i, chunk tid&7; k-major -> k-row (tid>>4)+16i, chunk tid&15
+  int rowi[4], krowi[4], cci[4];
+  int kc;
+  if constexpr (GLDS) {
+    kc = (lane & 7) ^ (lane >> 3);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m0 + rrow + 32 * i;
+      const int pi = wave * 4 + i;
+      rowi[i] = pi * 8 + (lane >> 3);
+      krowi[i] = pi * 4 + (lane >> 4);
+      const int pc = lane & 15;
+      cci[i] = ((((pc >> 1) ^ kmajor_swz(krowi[i])) << 1) | (pc & 1));
+    }
+  } else {
+    kc = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rowi[i] = (tid >> 3) + 32 * i;
+      krowi[i] = (tid >> 4) + 16 * i;
+      cci[i] = tid & 15;
+    }
+  }
+
+  long a_rowoff[4];   // !A_KM plain: element offset of the row (or -1)
+  RowPix a_pix[4];    // GATHER==1
+  long a_coloff[4];   // A_KM: column (element) of this thread's chunk (or -1)
+  long b_rowoff[4];
+  long b_coloff[4];
+  int b_ky[4], b_kx[4];  // GATHER==2: tap of the thread's column chunk
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (!A_KM) {
+      const int m = m0 + rowi[i];
       if constexpr (GATHER == 1) a_pix[i] = decompose_pixel(p.g, m, p.M);
       else a_rowoff[i] = m < p.M ? (long)m * p.lda : -1;
-    }
-  } else {
-    const int col = m0 + cc * 8;
-    a_coloff = col < p.M ? col : -1;
-  }
-  long b_rowoff[4];
-  long b_coloff = -1;
-  int b_ky = 0, b_kx = 0;  // GATHER==2: tap of this thread's column chunk
-  if constexpr (!B_KM) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = n0 + rrow + 32 * i;
-      b_rowoff[i] = n < p.N ? (long)n * p.ldb : -1;
-    }
-  } else {
-    const int col = n0 + cc * 8;
-    if constexpr (GATHER == 2) {
-      if (col < p.N) {
-        const uint32_t tap = fd_div((uint32_t)col, p.g.fd_cper);
-        b_coloff = col - (long)tap * p.g.cper;
-        b_ky = (int)fd_div(tap, p.g.fd_kw);
-        b_kx = (int)tap - b_ky * p.g.KW;
-      }
     } else {
-      b_coloff = col < p.N ? col : -1;
+      const int col = m0 + cci[i] * 8;
+      a_coloff[i] = col < p.M ? col : -1;
+    }
+    if constexpr (!B_KM) {
+      const int n = n0 + rowi[i];
+      b_rowoff[i] = n < p.N ? (long)n * p.ldb : -1;
+    } else {
+      const int col = n0 + cci[i] * 8;
+      b_coloff[i] = -1;
+      b_ky[i] = 0; b_kx[i] = 0;
+      if constexpr (GATHER == 2) {
+        if (col < p.N) {
+          const uint32_t tap = fd_div((uint32_t)col, p.g.fd_cper);
+          b_coloff[i] = col - (long)tap * p.g.cper;
+          b_ky[i] = (int)fd_div(tap, p.g.fd_kw);
+          b_kx[i] = (int)tap - b_ky[i] * p.g.KW;
+        }
+      } else {
+        b_coloff[i] = col < p.N ? col : -1;
+      }
     }
   }
 
-  bf16x8 ra[4], rb[4];
-
-  auto load_tiles = [&](int k0) {
-    // ---------------- A
+  // source address of chunk i of the A / B tile for the K step starting at k0
+  auto src_a = [&](int i, int k0) -> const bf16* {
     if constexpr (!A_KM) {
       const int kcol = k0 + kc * 8;
       const bool kvalid = kcol < kend;
@@ -188,45 +216,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         const uint32_t tap = fd_div((uint32_t)k0, p.g.fd_cper);
         const int c0 = k0 - (int)tap * p.g.cper;
         const int ky = (int)fd_div(tap, p.g.fd_kw), kx = (int)tap - ky * p.g.KW;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const long s = tap_src(p.g, a_pix[i], ky, kx);
-          const bf16* src = (s >= 0 && kvalid) ? Ab + s + c0 + kc * 8 : zp;
-          ra[i] = *(const bf16x8*)src;
-        }
+        const long s = tap_src(p.g, a_pix[i], ky, kx);
+        return (s >= 0 && kvalid) ? Ab + s + c0 + kc * 8 : zp;
       } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bf16* src = (a_rowoff[i] >= 0 && kvalid) ? Ab + a_rowoff[i] + kcol : zp;
-          ra[i] = *(const bf16x8*)src;
-        }
+        return (a_rowoff[i] >= 0 && kvalid) ? Ab + a_rowoff[i] + kcol : zp;
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = k0 + krow + 16 * i;
-        const bf16* src = (a_coloff >= 0 && k < kend) ? Ab + (long)k * p.lda + a_coloff : zp;
-        ra[i] = *(const bf16x8*)src;
-      }
+      const int k = k0 + krowi[i];
+      return (a_coloff[i] >= 0 && k < kend) ? Ab + (long)k * p.lda + a_coloff[i] : zp;
     }
-    // ---------------- B
+  };
+  auto src_b = [&](int i, int k0) -> const bf16* {
     if constexpr (!B_KM) {
       const int kcol = k0 + kc * 8;
-      const bool kvalid = kcol < kend;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bf16* src = (b_rowoff[i] >= 0 && kvalid) ? Bb + b_rowoff[i] + kcol : zp;
-        rb[i] = *(const bf16x8*)src;
-      }
+      return (b_rowoff[i] >= 0 && kcol < kend) ? Bb + b_rowoff[i] + kcol : zp;
     } else if constexpr (GATHER == 2) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = k0 + krow + 16 * i;
-        const RowPix px = decompose_pixel(p.g, k, kend);
-        const long s = tap_src(p.g, px, b_ky, b_kx);
-        const bf16* src = (s >= 0 && b_coloff >= 0) ? Bb + s + b_coloff : zp;
-        rb[i] = *(const bf16x8*)src;
-      }
+      const RowPix px = decompose_pixel(p.g, k0 + krowi[i], kend);
+      const long s = tap_src(p.g, px, b_ky[i], b_kx[i]);
+      return (s >= 0 && b_coloff[i] >= 0) ? Bb + s + b_coloff[i] : zp;
     } else {
       long tapoff = 0;
       int kbase = k0;
@@ -235,24 +242,39 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         kbase = k0 - (int)tap * p.g.cper;
         tapoff = (long)tap * p.b_tap_stride;
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = k0 + krow + 16 * i;
-        const bf16* src = (b_coloff >= 0 && k < kend) ? Bb + (long)(kbase + krow + 16 * i) * p.ldb + tapoff + b_coloff : zp;
-        rb[i] = *(const bf16x8*)src;
-      }
+      const int k = k0 + krowi[i];
+      return (b_coloff[i] >= 0 && k < kend) ? Bb + (long)(kbase + krowi[i]) * p.ldb + tapoff + b_coloff[i] : zp;
     }
   };
 
-  auto store_tiles = [&](int stage) {
+  bf16x8 ra[4], rb[4];  // register staging only
+
+  // GLDS: issue the 8 LDS-DMA loads of a K step into LDS stage `stage`
+  auto stage_glds = [&](int stage, int k0) {
+    unsigned char* sa = smem + stage * STAGE_BYTES + wave * 4096;
+    unsigned char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)src_a(i, k0), (lptr_t)(sa + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src_b(i, k0), (lptr_t)(sb + i * 1024), 16, 0, 0);
+    }
+  };
+  auto load_regs = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *(const bf16x8*)src_a(i, k0);
+      rb[i] = *(const bf16x8*)src_b(i, k0);
+    }
+  };
+  auto store_regs = [&](int stage) {
     unsigned char* sa = smem + stage * STAGE_BYTES;
     unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if constexpr (!A_KM) *(bf16x8*)(sa + kc_off(rrow + 32 * i, kc)) = ra[i];
-      else *(bf16x8*)(sa + km_off(krow + 16 * i, cc)) = ra[i];
-      if constexpr (!B_KM) *(bf16x8*)(sb + kc_off(rrow + 32 * i, kc)) = rb[i];
-      else *(bf16x8*)(sb + km_off(krow + 16 * i, cc)) = rb[i];
+      if constexpr (!A_KM) *(bf16x8*)(sa + kc_off(rowi[i], kc)) = ra[i];
+      else *(bf16x8*)(sa + km_off(krowi[i], cci[i])) = ra[i];
+      if constexpr (!B_KM) *(bf16x8*)(sb + kc_off(rowi[i], kc)) = rb[i];
+      else *(bf16x8*)(sb + km_off(krowi[i], cci[i])) = rb[i];
     }
   };
 
@@ -263,15 +285,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) {
-    load_tiles(kbeg);
-    store_tiles(0);
+    if constexpr (GLDS) stage_glds(0, kbeg);
+    else { load_regs(kbeg); store_regs(0); }
   }
-  __syncthreads();
+  __syncthreads();  // (hipcc drains the outstanding LDS-DMA with vmcnt(0) ahead of the barrier)
 
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    if (more) load_tiles(kbeg + (kt + 1) * TBK);
+    if (more) {
+      if constexpr (GLDS) stage_glds(cur ^ 1, kbeg + (kt + 1) * TBK);
+      else load_regs(kbeg + (kt + 1) * TBK);
+    }
     const unsigned char* sa = smem + cur * STAGE_BYTES;
     const unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
@@ -287,13 +312,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tiles(cur ^ 1);
+    if constexpr (!GLDS) {
+      if (more) store_regs(cur ^ 1);
+    }
     __syncthreads();
     cur ^= 1;
   }
 
   // ---- epilogue: lane holds C[m = ..+(lane&15)][n = ..+4*(lane>>4)+r]
   const int r16 = lane & 15, g = lane >> 4;
+  f32x4 bias4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + j * 16 + 4 * g;
+    bias4[j] = (p.bias && p.split_k <= 1 && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + r16;
@@ -305,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
       if (p.split_k > 1) {
         *(f32x4*)(p.ws + ((long)blockIdx.y * p.M + m) * p.N + n) = acc[i][j];
       } else {
-        gemm_epilogue4<bf16>(p, m, n, acc[i][j]);
+        gemm_epilogue4b<bf16>(p, m, n, acc[i][j], bias4[j]);
       }
     }
   }
@@ -313,17 +346,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 
 size_t gemm_splitk_ws_bytes(int M, int N, int split_k) { return split_k > 1 ? (size_t)split_k * M * N * sizeof(float) : 0; }
 
-template <bool A_KM, bool B_KM, int GATHER>
-static int launch_variant(const GemmParams& p, hipStream_t st) {
+template <bool A_KM, bool B_KM, int GATHER, bool GLDS>
+static int launch_variant2(const GemmParams& p, hipStream_t st) {
   const int ntm = cdiv(p.M, TBM), ntn = cdiv(p.N, TBN);
   dim3 grid(ntm * ntn, p.split_k > 1 ? p.split_k : 1, 1);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<A_KM, B_KM, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<A_KM, B_KM, GATHER, GLDS>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<A_KM, B_KM, GATHER>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<A_KM, B_KM, GATHER, GLDS>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
   MMSA_CHECK_LAUNCH();
   if (p.split_k > 1) {
     const long total4 = (long)p.M * p.N / 4;
@@ -335,8 +368,18 @@ static int launch_variant(const GemmParams& p, hipStream_t st) {
   return MMSA_OK;
 }
 
+static bool use_regstage() {
+  const char* v = getenv("MMSA_GEMM_REGSTAGE");
+  return v && atoi(v) != 0;
+}
+
+template <bool A_KM, bool B_KM, int GATHER>
+static int launch_variant(const GemmParams& p, hipStream_t st) {
+  return use_regstage() ? launch_variant2<A_KM, B_KM, GATHER, false>(p, st) : launch_variant2<A_KM, B_KM, GATHER, true>(p, st);
+}
+
 // ---- optional live timing of the MFMA GEMM launches (bench.py roofline): HIP events on the launch stream ----------
-struct ProfRec { hipEvent_t a, b; double flop; };
+struct ProfRec { hipEvent_t a, b; double flop; int M, N, K, akm, bkm, gather, split; };
 static std::vector<ProfRec> g_prof;
 static size_t g_prof_used = 0;
 static bool g_prof_on = false;
@@ -364,6 +407,19 @@ int gemm_prof_end(double* total_ms, double* total_flop, long* launches) {
     fl += g_prof[i].flop;
   }
   *total_ms = ms; *total_flop = fl; *launches = (long)g_prof_used;
+  if (const char* path = getenv("MMSA_PROF_DUMP")) {  // per-launch table for the profiles/ directory
+    if (FILE* f = fopen(path, "w")) {
+      fprintf(f, "M,N,K,a_kmajor,b_kmajor,gather,split_k,us,tflops\n");
+      for (size_t i = 0; i < g_prof_used; ++i) {
+        float t = 0;
+        (void)hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
+        const ProfRec& r = g_prof[i];
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.1f\n", r.M, r.N, r.K, r.akm, r.bkm, r.gather, r.split, t * 1e3,
+                t > 0 ? r.flop / (t * 1e-3) / 1e12 : 0.0);
+      }
+      fclose(f);
+    }
+  }
   g_prof_used = 0;
   return MMSA_OK;
 }
@@ -374,6 +430,7 @@ int gemm_bf16_launch(const GemmParams& pin, hipStream_t st) {
   if (!g_prof_on || g_prof_used >= g_prof.size()) return gemm_bf16_launch_inner(pin, st);
   ProfRec& r = g_prof[g_prof_used];
   r.flop = 2.0 * pin.M * pin.N * (double)pin.K;
+  r.M = pin.M; r.N = pin.N; r.K = pin.K; r.akm = pin.a_kmajor; r.bkm = pin.b_kmajor; r.gather = pin.gather; r.split = pin.split_k;
   (void)hipEventRecord(r.a, st);
   const int rc = gemm_bf16_launch_inner(pin, st);
   (void)hipEventRecord(r.b, st);
