@@ -60,21 +60,42 @@ class GradReducer:
             torch.cuda.current_stream(self.flat_g.device).wait_stream(self.stream)
 
 
+class FlatAdamW:
+    """clip_grad_norm_(max_norm) + AdamW over a FlatState's buffers (two kernels): Trainer.py:19-21,80-81."""
+
+    def __init__(self, state, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0):
+        self.state, self.lr, self.wd, self.betas, self.eps, self.max_norm = state, lr, weight_decay, betas, eps, max_norm
+        dev = state.flat_w.device
+        n = state.flat_w.numel()
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.t = 0
+        self.norm_ws = torch.empty(_lib.load().mmsa_grad_norm_ws_bytes(), dtype=torch.uint8, device=dev)
+        self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)  # [total norm, clip coefficient]
+
+    def step(self, grad_scale=1.0):
+        L = _lib.load()
+        st = self.state
+        n = st.flat_w.numel()
+        check(L.mmsa_grad_norm(ptr(st.flat_g), n, grad_scale, self.max_norm, ptr(self.norm_out), ptr(self.norm_ws),
+                               stream_ptr()), "mmsa_grad_norm")
+        self.t += 1
+        check(L.mmsa_adamw_step(ptr(st.flat_w), ptr(st.flat_g), ptr(self.m), ptr(self.v), ptr(st.flat_wt), n, self.lr,
+                                self.betas[0], self.betas[1], self.eps, self.wd, self.t, ptr(self.norm_out), grad_scale,
+                                stream_ptr()), "mmsa_adamw_step")
+        for e, _, _ in st.ranges:
+            if not isinstance(e, HeadEngine):
+                e.mark_weights_fresh()
+
+
 class FusedTrainStep:
     """model: MultimodalTransformerModel (Trainer contract). One call = one optimizer step."""
 
     def __init__(self, model, device, precision="bf16", lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
                  max_norm=1.0, bucket_bytes=64 << 20):
         self.model, self.device = model, torch.device(device)
-        self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
         self.state = materialize(model, self.device, precision)
-        n = self.state.flat_w.numel()
-        self.m = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.v = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.t = 0
-        L = _lib.load()
-        self.norm_ws = torch.empty(L.mmsa_grad_norm_ws_bytes(), dtype=torch.uint8, device=self.device)
-        self.norm_out = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self.opt = FlatAdamW(self.state, lr, weight_decay, betas, eps, max_norm)
         self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.reducer = GradReducer(self.state.flat_g, bucket_bytes) if self.world > 1 else None
@@ -105,16 +126,13 @@ class FusedTrainStep:
         logits.backward(dlogits)
         if self.reducer is not None:
             self.reducer.finish()
-        scale = 1.0 / self.world
-        st = self.state
-        n = st.flat_w.numel()
-        check(L.mmsa_grad_norm(ptr(st.flat_g), n, scale, self.max_norm, ptr(self.norm_out), ptr(self.norm_ws), stream_ptr()),
-              "mmsa_grad_norm")
-        self.t += 1
-        check(L.mmsa_adamw_step(ptr(st.flat_w), ptr(st.flat_g), ptr(self.m), ptr(self.v), ptr(st.flat_wt), n, self.lr,
-                                self.betas[0], self.betas[1], self.eps, self.wd, self.t, ptr(self.norm_out), scale,
-                                stream_ptr()), "mmsa_adamw_step")
-        for e, _, _ in st.ranges:
-            if not isinstance(e, HeadEngine):
-                e.mark_weights_fresh()
+        self.opt.step(1.0 / self.world)
         return self.loss, logits
+
+    @property
+    def lr(self):
+        return self.opt.lr
+
+    @lr.setter
+    def lr(self, v):
+        self.opt.lr = v

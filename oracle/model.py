@@ -77,9 +77,10 @@ def train_step(sd, param_names, image, token_ids, attention_mask, labels, cfg, o
     logits, _ = model_forward(work, image, token_ids, attention_mask, cfg, True, pol)
     loss = F_.cross_entropy(logits, labels)
     grads_t = torch.autograd.grad(loss, [params[n] for n in param_names], allow_unused=True)
-    grads = {n: (g if g is not None else torch.zeros_like(sd[n])) for n, g in zip(param_names, grads_t)}
+    # parameters that received no gradient are skipped entirely (no decay either), as torch.optim.AdamW does for grad None
+    grads = {n: g for n, g in zip(param_names, grads_t) if g is not None}
     raw = {n: g.clone() for n, g in grads.items()}
     total = clip_grad_norm(list(grads.values()), max_norm)
     with torch.no_grad():
-        adamw_step({n: sd[n] for n in param_names}, grads, opt_state, lr, weight_decay)
+        adamw_step({n: sd[n] for n in grads}, grads, opt_state, lr, weight_decay)
     return loss.detach(), logits.detach(), raw, total

@@ -1,0 +1,80 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient path. (a) GradReducer sums bucketed ranges identically on both
+ranks; (b) averaging the per-rank gradients of two half batches equals the gradient of the whole batch (BN in eval
+mode, as SURVEY.md §8e prescribes), using the oracle fusion head as the differentiable function."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _head_loss(sd, f, labels):
+    from oracle import fusion as OF
+    e2p = OF.cross_modal_transformer(sd, "cross_attn_e2p", f[0], f[1], f[1])
+    p2e = OF.cross_modal_transformer(sd, "cross_attn_p2e", f[0], f[2], f[2])
+    logits, _ = OF.weighted_fusion_logits(sd, f[0], f[1], f[2], e2p, p2e, False)
+    return OF.cross_entropy(logits, labels)
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodal_sentiment_aanalysis_amd.fused import GradReducer
+    d = np.load(os.path.join(G, "a7_train_step.npz"))
+    sd = {k[3:]: torch.from_numpy(d[k]).clone() for k in d.files if k.startswith("w0.")}
+    names = [k for k in sd if "running" not in k and "num_batches" not in k and not k.startswith("valence_head")
+             and k not in ("contrastive_weight", "temperature")]
+    f = [torch.from_numpy(d[f"f{i}"]) for i in range(3)]
+    labels = torch.from_numpy(d["labels"])
+    half = slice(rank * 8, rank * 8 + 8)
+    params = {n: sd[n].requires_grad_(True) for n in names}
+    work = dict(sd); work.update(params)
+    loss = _head_loss(work, [x[half] for x in f], labels[half])
+    gs = torch.autograd.grad(loss, [params[n] for n in names], allow_unused=True)
+    sizes = [sd[n].numel() for n in names]
+    flat = torch.cat([(g if g is not None else torch.zeros_like(sd[n])).reshape(-1) for n, g in zip(names, gs)])
+    red = GradReducer(flat, bucket_bytes=64 << 10)  # many small buckets
+    assert len(red.buckets(0, flat.numel())) > 4
+    # reduce in two engine-like ranges, like the per-engine hooks do
+    cut = sum(sizes[: len(sizes) // 2])
+    red.reduce_range(cut, flat.numel() - cut)
+    red.reduce_range(0, cut)
+    red.finish()
+    flat /= world
+    torch.save(flat, os.path.join(out, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_equals_full_batch(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0 = torch.load(os.path.join(tmp_path, "g0.pt"), weights_only=True)
+    g1 = torch.load(os.path.join(tmp_path, "g1.pt"), weights_only=True)
+    assert torch.equal(g0, g1), "all-reduced gradients must be bit-identical across ranks"
+    d = np.load(os.path.join(G, "a7_train_step.npz"))
+    sd = {k[3:]: torch.from_numpy(d[k]).clone() for k in d.files if k.startswith("w0.")}
+    names = [k for k in sd if "running" not in k and "num_batches" not in k and not k.startswith("valence_head")
+             and k not in ("contrastive_weight", "temperature")]
+    params = {n: sd[n].requires_grad_(True) for n in names}
+    work = dict(sd); work.update(params)
+    f = [torch.from_numpy(d[f"f{i}"]) for i in range(3)]
+    loss = _head_loss(work, f, torch.from_numpy(d["labels"]))
+    gs = torch.autograd.grad(loss, [params[n] for n in names], allow_unused=True)
+    full = torch.cat([(g if g is not None else torch.zeros_like(sd[n])).reshape(-1) for n, g in zip(names, gs)])
+    assert (g0 - full).abs().max().item() < 1e-6 * max(1.0, full.abs().max().item())

@@ -1,0 +1,268 @@
+"""GPU: the HIP product path against the golden vectors generated from the reference's own modules
+(tests/golden/*.npz) — the same fixtures that pin the oracle on the CPU (test_oracle_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import multimodal_sentiment_aanalysis_amd as mm
+from multimodal_sentiment_aanalysis_amd.engine import BertTextNet, HeadEngine, materialize
+from multimodal_sentiment_aanalysis_amd.fused import FlatAdamW
+from multimodal_sentiment_aanalysis_amd._lib import HEAD_MM_FUSION, HEAD_WEIGHTED
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    d = np.load(os.path.join(G, name))
+    return {k: torch.from_numpy(np.array(d[k])) for k in d.files}
+
+
+def sub(d, prefix):
+    return {k[len(prefix):]: v.clone() for k, v in d.items() if k.startswith(prefix)}
+
+
+def close(a, b, tol, what, floor=0.0):
+    scale = max(b.double().abs().max().item(), floor, 1e-12)
+    err = (a.detach().cpu().double() - b.double()).abs().max().item() / scale
+    assert err < tol, f"{what}: {err:.3e}"
+
+
+def check_param_grads(module, d, prefix, tol, what):
+    gs = {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+    gmax = max(v.abs().max().item() for v in gs.values())
+    for n, p in module.named_parameters():
+        if n in gs:
+            assert p.grad is not None, n
+            close(p.grad, gs[n], tol, f"{what} grad {n}", floor=1e-3 * gmax)
+
+
+@pytest.mark.parametrize("tag", ["l1", "l4"])
+def test_a1_cross_modal_transformer(dev, tag):
+    d = load(f"a1_cross_modal_{tag}.npz")
+    m = mm.CrossModalTransformer()
+    m.load_state_dict(sub(d, "w."))
+    m.to(dev)
+    q, k, v = (d[n].to(dev).requires_grad_(True) for n in ("q", "k", "v"))
+    out = m(q, k, v)
+    close(out, d["out"], 5e-6, "A1 out")
+    (out * d["wgt"].to(dev)).sum().backward()
+    close(q.grad, d["dq"], 5e-5, "dq"); close(k.grad, d["dk"], 5e-5, "dk"); close(v.grad, d["dv"], 5e-5, "dv")
+    check_param_grads(m, d, "g.", 1e-4, "A1")
+
+
+class _Fusion3(HeadEngine):
+    """The reference's 3-modality ME-MHACL fusion (MultimodalModel.py:388-404) on the kind-1 engine."""
+    kind = HEAD_MM_FUSION
+
+    def __init__(self, pool):
+        super().__init__()
+        self.pool = pool
+        self._init_head()
+
+    def _base_cfg(self):
+        c = super()._base_cfg()
+        c.update(embed=256, heads=8, tokens=3, pool_mode=0 if self.pool == "max" else 1)
+        return c
+
+    def _out_dims(self):
+        return [256]
+
+
+def test_a2_mm_fusion(dev):
+    d = load("a2_mm_fusion.npz")
+    for mode in ("train", "eval"):
+        m = _Fusion3("max")
+        m.load_state_dict(sub(d, "w."))
+        m.to(dev).train(mode == "train")
+        feats = [d[f"f{i}"].to(dev).requires_grad_(True) for i in range(3)]
+        out = m._run(*feats)[0]
+        close(out, d[f"{mode}.out"], 1e-5, f"A2 {mode} out")
+        (out * d["wgt"].to(dev)).sum().backward()
+        for i in range(3):
+            close(feats[i].grad, d[f"{mode}.df{i}"], 2e-4, f"A2 {mode} df{i}")
+        check_param_grads(m, d, f"{mode}.g.", 2e-4, f"A2 {mode}")
+        if mode == "train":
+            sd = m.state_dict()
+            for k2 in ("fusion_mlp.2.running_mean", "fusion_mlp.2.running_var"):
+                close(sd[k2], d["train.post." + k2], 1e-5, k2)
+    m = _Fusion3("mean")
+    m.load_state_dict(sub(d, "w."))
+    m.to(dev).eval()
+    with torch.no_grad():
+        out = m._run(*[d[f"f{i}"].to(dev) for i in range(3)])[0]
+    close(out, d["eval.mean_pool_out"], 1e-5, "A2 mean-pool twin")
+
+
+class _RefHead(HeadEngine):
+    """Reference MultimodalTransformerModel fusion path (:287-313) with identity encoders: two CrossModalTransformers
+    + the weighted head (with the valence head), using the reference's module names so its state_dict loads."""
+    kind = HEAD_WEIGHTED
+
+    def __init__(self, valence=True):
+        super().__init__()
+        self.valence = valence
+        self.cross_attn_e2p = mm.CrossModalTransformer()
+        self.cross_attn_p2e = mm.CrossModalTransformer()
+        self._init_head()
+
+    def _base_cfg(self):
+        c = super()._base_cfg()
+        c.update(embed=256, num_classes=3, valence=int(self.valence), dropout_p=0.0)
+        return c
+
+    def _out_dims(self):
+        return [3, 128] + ([3] if self.valence else [])
+
+    def forward(self, eeg, eye, pps):
+        e2p = self.cross_attn_e2p(eeg, eye, eye)
+        p2e = self.cross_attn_p2e(eeg, pps, pps)
+        return self._run(eeg, eye, pps, e2p, p2e)
+
+
+def test_a4_fusion_head(dev):
+    d = load("a4_fusion_head.npz")
+    for mode in ("train", "eval"):
+        m = _RefHead()
+        m.load_state_dict(sub(d, "w."), strict=False)  # contrastive_weight / temperature are not part of this path
+        materialize(m, dev)
+        m.train(mode == "train")
+        f = [d[f"f{i}"].to(dev).requires_grad_(True) for i in range(3)]
+        outs = m(*f)
+        close(outs[0], d[f"{mode}.arousal"], 2e-5, f"A4 {mode} arousal")
+        close(outs[2], d[f"{mode}.valence"], 2e-5, f"A4 {mode} valence")
+        ((outs[0] * d["wa"].to(dev)).sum() + (outs[2] * d["wv"].to(dev)).sum()).backward()
+        for i in range(3):
+            close(f[i].grad, d[f"{mode}.df{i}"], 5e-4, f"A4 {mode} df{i}")
+        check_param_grads(m, d, f"{mode}.g.", 1e-3, f"A4 {mode}")
+        if mode == "train":
+            sd = m.state_dict()
+            for k2 in [k for k in d if k.startswith("train.post.")]:
+                close(sd[k2[len("train.post."):]], d[k2], 2e-5, k2)
+
+
+def test_a5_a6_heads_and_ce(dev):
+    d = load("a5_a6_heads_ce.npz")
+    c = mm.Classifier()
+    c.dropout_p = 0.0
+    c.load_state_dict(sub(d, "cls.w."))
+    c.to(dev).train()
+    x = d["x"].to(dev).requires_grad_(True)
+    a, v = c(x)
+    close(a, d["cls_a"], 5e-6, "cls a"); close(v, d["cls_v"], 5e-6, "cls v")
+    ((a * d["wa"].to(dev)).sum() + (v * d["wv"].to(dev)).sum()).backward()
+    close(x.grad, d["cls_dx"], 5e-5, "cls dx")
+    check_param_grads(c, d, "cls.g.", 5e-5, "classifier")
+    p = mm.ProjectionHead()
+    p.dropout_p = 0.0
+    p.load_state_dict(sub(d, "proj.w."))
+    p.to(dev).train()
+    x = d["x"].to(dev).requires_grad_(True)
+    z = p(x)
+    close(z, d["proj_z"], 1e-5, "proj z")
+    (z * d["wz"].to(dev)).sum().backward()
+    close(x.grad, d["proj_dx"], 2e-4, "proj dx")
+    check_param_grads(p, d, "proj.g.", 2e-4, "projection head")
+    lg = d["ce_logits"].to(dev).requires_grad_(True)
+    loss = mm.CrossEntropyLoss()(lg, d["ce_labels"].to(dev))
+    assert abs(loss.item() - d["ce_loss"].item()) < 1e-6
+    loss.backward()
+    close(lg.grad, d["ce_dlogits"], 1e-6, "CE dlogits")
+
+
+def test_a7_train_step_fused_optimizer(dev):
+    """Two reference train steps (Trainer.py:59-81) through the HIP CE / grad-norm / AdamW kernels on the flat buffers."""
+    d = load("a7_train_step.npz")
+    m = _RefHead(valence=False)  # the older single-head contract trains the arousal head only
+    m.load_state_dict({k: v for k, v in sub(d, "w0.").items() if not k.startswith("valence_head")}, strict=False)
+    state = materialize(m, dev)
+    m.train()
+    opt = FlatAdamW(state, lr=1e-4, weight_decay=0.01, max_norm=1.0)
+    f = [d[f"f{i}"].to(dev) for i in range(3)]
+    labels = d["labels"].to(dev)
+    crit = mm.CrossEntropyLoss()
+    for step in (1, 2):
+        state.flat_g.zero_()
+        loss = crit(m(*f)[0], labels)
+        loss.backward()
+        opt.step()
+        assert abs(loss.item() - d[f"loss{step}"].item()) < 1e-5
+        assert abs(opt.norm_out[0].item() - d[f"norm{step}"].item()) / d[f"norm{step}"].item() < 1e-4
+        grads = {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+        gmax = max(g.abs().max().item() for g in grads.values())
+        for n, p in m.named_parameters():
+            diff = (p.detach().cpu().double() - d[f"w{step}.{n}"].double()).abs()
+            assert diff.max().item() <= 2.2e-4 * step, f"step {step} {n}: {diff.max().item():.3e}"
+            if grads[n].abs().max().item() >= 1e-5 * gmax:
+                assert (diff > 2e-6).double().mean().item() < 2e-3, f"step {step} {n}"
+
+
+def test_e1_bert_mini_against_transformers(dev):
+    d = load("e1_bert_mini.npz")
+    cfg = dict(hidden=128, layers=2, heads=2, intermediate=512, vocab=1000, max_pos=64, type_vocab=2, ln_eps=1e-12)
+    net = BertTextNet(cfg)
+    net.precision = "fp32"
+    hf = {"bert." + k[2:]: v for k, v in d.items() if k.startswith("w.")}
+    # make the projection read the pooled output back: proj = [I_128 ; 0] so feat[:, :128] == pooled
+    proj_w = torch.zeros(256, 128)
+    proj_w[:128] = torch.eye(128)
+    hf["proj.weight"], hf["proj.bias"] = proj_w, torch.zeros(256)
+    net.load_state_dict(hf)
+    net.to(dev)
+    with torch.no_grad():
+        out = net(d["ids"].to(dev))
+        close(out[:, :128], d["pooled_nomask"], 5e-5, "pooled (HF golden)")
+        out = net(d["ids"].to(dev), d["mask"].to(dev))
+        close(out[:, :128], d["pooled_mask"], 5e-5, "pooled masked (HF golden)")
+
+
+def test_e1_bert_base_seed_regenerated(dev):
+    from multimodal_sentiment_aanalysis_amd.engine import BERT_BASE
+    d = load("e1_bert_base_seed1234.npz")
+    torch.manual_seed(1234)
+    net = BertTextNet(BERT_BASE)
+    net.precision = "fp32"
+    with torch.no_grad():
+        net._pmap["proj.weight"].zero_()
+        net._pmap["proj.weight"][:256, :256] = torch.eye(256)
+        net._pmap["proj.bias"].zero_()
+    net.to(dev)
+    with torch.no_grad():
+        out = net(d["ids"].to(dev))
+    close(out, d["pooled"][:, :256], 2e-4, "BERT-base pooled[:, :256] (HF golden), fp32 engine")
+    net.precision = "bf16"
+    materialize(net, dev)
+    with torch.no_grad():
+        out16 = net(d["ids"].to(dev))
+    err = (out16.cpu() - d["pooled"][:, :256]).abs().max().item()
+    print(f"BERT-base bf16 engine vs HF fp32 pooled: max abs err {err:.3e}")
+    assert err < 5e-2
+
+
+def test_trainer_and_tester_contracts(dev, tmp_path):
+    from multimodal_sentiment_aanalysis_amd.dataLoader import MultimodalDataLoader
+    from multimodal_sentiment_aanalysis_amd.Tester import Tester
+    from multimodal_sentiment_aanalysis_amd.Trainer import Trainer
+    from util import MINI_BERT, MINI_RESNET
+    torch.manual_seed(0)
+    dl = MultimodalDataLoader(None, batch_size=8, n=48, seq_len=16, image_size=64, vocab=1000)
+    train, test = dl.dict_loader(1, True), dl.dict_loader(1, False)
+    for fused in (True, False):
+        model = mm.MultimodalTransformerModel(bert_config=MINI_BERT, resnet_config=MINI_RESNET)
+        tr = Trainer(model, train, test, device="cuda", fused=fused, precision="fp32")
+        l0 = tr.train_epoch(1)
+        l1 = tr.train_epoch(2)
+        assert all(x == x for x in l0 + l1) and 0.0 <= l1[3] <= 1.0
+        te = tr.test()
+        assert te[0] == te[0]
+    os.chdir(tmp_path)
+    torch.save({"module." + k: v for k, v in model.state_dict().items()}, "ddp_style.pth")
+    t = Tester(model, test, device="cuda")
+    res = t.run("ddp_style.pth")  # `module.` prefix is stripped (Tester.py:32-33)
+    assert set(res) == {"loss", "accuracy", "predictions", "labels", "probabilities"}
+    assert res["probabilities"].shape == (2, 3) and abs(res["probabilities"].sum(1) - 1).max() < 1e-5
+    single = t.predict_single({k: v[0] for k, v in next(iter(test))[0].items()})
+    assert single["probabilities"].shape == (3,)
