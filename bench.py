@@ -45,7 +45,11 @@ def cpu_baseline(model, B, steps):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # one GPU's host share on the pool is 16 cores; more threads than that make the fp32 oracle slower, not faster
+    # (measured on the 2x64-core host: 32 threads 1.8 s/step, 128 threads 7.9 s/step at B=8)
+    cores = min(cores, 16)
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle train step on {cores} threads ...", file=sys.stderr, flush=True)
     sd = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
     names = [n for n, _ in model.named_parameters() if n not in ("contrastive_weight", "temperature")]
     cfg = dict(bert=OB, resnet=OR)
@@ -68,7 +72,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--cpu-baseline-steps", type=int, default=2)
+    ap.add_argument("--cpu-baseline-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -55,17 +55,18 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restri
 }
 
 // finalize kernels: 256 threads = 16 columns x 16 partial-lanes (fixed summation tree, see partial_finalize_kernel)
-#define BN_FIN_COLS 16
+#define BN_FIN_COLS 4
+#define BN_FIN_LANES 64
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int M, int C,
                                                                 float eps, float momentum, float* __restrict__ mean,
                                                                 float* __restrict__ invstd, float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var) {
-  __shared__ double rs[16][17], rq[16][17];
-  const int cc = threadIdx.x & 15, r = threadIdx.x >> 4;
+  __shared__ double rs[BN_FIN_LANES][BN_FIN_COLS + 1], rq[BN_FIN_LANES][BN_FIN_COLS + 1];
+  const int cc = threadIdx.x & (BN_FIN_COLS - 1), r = threadIdx.x / BN_FIN_COLS;
   const int c = blockIdx.x * BN_FIN_COLS + cc;
   double s = 0, q = 0;
   if (c < C)
-    for (int b = r; b < chunks; b += 16) {
+    for (int b = r; b < chunks; b += BN_FIN_LANES) {
       s += part[((long)b * 2 + 0) * C + c];
       q += part[((long)b * 2 + 1) * C + c];
     }
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
   if (r != 0 || c >= C) return;
   s = 0; q = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { s += rs[k][cc]; q += rq[k][cc]; }
+  for (int k = 0; k < BN_FIN_LANES; ++k) { s += rs[k][cc]; q += rq[k][cc]; }
   const double mu = s / M;
   double var = q / M - mu * mu;
   if (var < 0) var = 0;
@@ -174,12 +175,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C,
                                                               float* __restrict__ sums, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate) {
-  __shared__ float rs[16][17], rq[16][17];
-  const int cc = threadIdx.x & 15, r = threadIdx.x >> 4;
+  __shared__ float rs[BN_FIN_LANES][BN_FIN_COLS + 1], rq[BN_FIN_LANES][BN_FIN_COLS + 1];
+  const int cc = threadIdx.x & (BN_FIN_COLS - 1), r = threadIdx.x / BN_FIN_COLS;
   const int c = blockIdx.x * BN_FIN_COLS + cc;
   float s = 0, q = 0;
   if (c < C)
-    for (int b = r; b < chunks; b += 16) {
+    for (int b = r; b < chunks; b += BN_FIN_LANES) {
       s += part[((long)b * 2 + 0) * C + c];
       q += part[((long)b * 2 + 1) * C + c];
     }
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   if (r != 0 || c >= C) return;
   s = 0; q = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { s += rs[k][cc]; q += rq[k][cc]; }
+  for (int k = 0; k < BN_FIN_LANES; ++k) { s += rs[k][cc]; q += rq[k][cc]; }
   sums[c] = s;
   sums[C + c] = q;
   if (dgamma) {
@@ -238,7 +239,7 @@ static int bn_forward_t(const T* x, const float* gamma, const float* beta, float
                         int act, int training, hipStream_t st) {
   const BnMap m = bn_map(C);
   if (training) {
-    const int rpc = max(cdiv(M, BN_CHUNKS), m.rlanes);
+    const int rpc = max(cdiv(M, BN_CHUNKS), m.rlanes * 16);
     const int chunks = cdiv(M, rpc);
     hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(chunks, m.cgroups), dim3(256), 0, st, x, ws, M, C, m.cthreads, rpc);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, BN_FIN_COLS)), dim3(256), 0, st, (const float*)ws, chunks, M, C, eps,
@@ -271,7 +272,7 @@ static int bn_backward_t(const T* dy, const T* x, const T* y, const float* mean,
                          const float* beta, T* dx, T* dres, float* dgamma, float* dbeta, int accumulate, float* ws, int M,
                          int C, int act, int training, hipStream_t st) {
   const BnMap m = bn_map(C);
-  const int rpc = max(cdiv(M, BN_CHUNKS), m.rlanes);
+  const int rpc = max(cdiv(M, BN_CHUNKS), m.rlanes * 16);
   const int chunks = cdiv(M, rpc);
   float* sums = ws + (size_t)BN_CHUNKS * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(chunks, m.cgroups), dim3(256), 0, st, dy, x, y, mean, invstd, gamma,

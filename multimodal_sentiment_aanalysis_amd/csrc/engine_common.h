@@ -90,7 +90,19 @@ struct Eng {
     p.A = x; p.lda = ldx; p.B = W; p.ldb = K; p.C = y; p.ldc = ldy;
     p.M = M; p.N = N; p.K = K;
     p.bias = bias; p.act = act; p.C2 = pre; p.ldc2 = N; p.add = add; p.ldadd = ldadd; p.out_f32 = out_f32;
+    small_split(p);
     return gemm(p);
+  }
+  // fp32 SIMT GEMMs of the fusion head have M = batch rows: a handful of workgroups each walking the whole K serially.
+  // Split K over workgroups (the reducer applies the epilogue) so the launch is a few microseconds instead of ~25.
+  void small_split(GemmParams& p) const {
+    if (dtype != MMSA_F32 || (p.N % 4) || p.K < 256) return;
+    const long tiles = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
+    if (tiles >= 64) return;
+    int split = p.K / 64;
+    if (split > 16) split = 16;
+    while (split > 1 && (size_t)split * p.M * p.N * sizeof(float) > splitk_bytes) --split;
+    if (split > 1) { p.split_k = split; p.ws = splitk_ws; }
   }
   // dx[M,K] = dy[M,N] W[N,K]  (* gelu'(mul)) (+ add)
   int linear_dgrad(const void* dy, long lddy, const void* W, void* dx, long lddx, int M, int N, int K,
@@ -99,6 +111,7 @@ struct Eng {
     p.A = dy; p.lda = lddy; p.B = W; p.ldb = K; p.b_kmajor = 1; p.C = dx; p.ldc = lddx;
     p.M = M; p.N = K; p.K = N;
     p.mul = mul; p.ldmul = ldmul; p.add = add; p.ldadd = ldadd;
+    small_split(p);
     return gemm(p);
   }
   int pick_split(int Mo, int No, int Kred) const {
