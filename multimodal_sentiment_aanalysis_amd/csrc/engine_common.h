@@ -69,9 +69,23 @@ struct Eng {
     const char* v = getenv("MMSA_BF16_SIMT");  // read per call so a test can toggle it inside one process
     return v && atoi(v) != 0;
   }
-  int gemm(const GemmParams& p) const {
-    if (dtype != MMSA_BF16) return gemm_f32_launch(p, st);
-    return force_simt() ? gemm_bf16_simt_launch(p, st) : gemm_bf16_launch(p, st);
+  int gemm(const GemmParams& pin) const {
+    if (dtype != MMSA_BF16) return gemm_f32_launch(pin, st);
+    if (force_simt()) return gemm_bf16_simt_launch(pin, st);
+    // Few-tile, deep-K launches (stage-3/4 convolutions: 100-200 tiles of 128x128 for 256 CUs x 2 slots) get a split
+    // over K so that the machine is filled; the slab reducer applies the epilogue.
+    GemmParams p = pin;
+    if (p.split_k <= 1 && splitk_ws && !(p.N % 4)) {
+      const long tiles = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
+      if (tiles <= 200 && p.K >= 1024) {
+        int split = (int)(512 / tiles);
+        if (split > p.K / 512) split = p.K / 512;
+        if (split > 8) split = 8;
+        while (split > 1 && (size_t)split * p.M * p.N * sizeof(float) > splitk_bytes) --split;
+        if (split > 1) { p.split_k = split; p.ws = splitk_ws; }
+      }
+    }
+    return gemm_bf16_launch(p, st);
   }
   int attn_impl() const { return dtype != MMSA_BF16 ? 0 : (force_simt() ? 2 : 1); }
 
@@ -120,7 +134,7 @@ struct Eng {
     int split = (int)(512 / (tiles > 0 ? tiles : 1));
     const int maxs = Kred / 256;
     if (split > maxs) split = maxs;
-    if (split > 64) split = 64;
+    if (split > 256) split = 256;
     if (split < 1) split = 1;
     while (split > 1 && (size_t)split * Mo * No * sizeof(float) > splitk_bytes) --split;
     return split;

@@ -57,6 +57,9 @@ struct GemmParams {
   int split_k;
   float* ws;
   const void* zero_page;  // >= 64 bytes of zeros in device memory (source for padded taps)
+  // filled by the MFMA launcher: byte extents of the A / B views for the buffer-descriptor staging path
+  unsigned a_bytes, b_bytes;
+  int use_srd;
 };
 
 int gemm_bf16_launch(const GemmParams& p, hipStream_t st);

@@ -19,6 +19,7 @@
 // stride hole, row/col/k past the end) is redirected to a page of zeros, so the main loop is branch-free.
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 #include "gemm.h"
 #include "gemm_epilogue.h"
@@ -249,10 +250,52 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 
   bf16x8 ra[4], rb[4];  // register staging only
 
+  // Plain (non-gather) operands go through buffer descriptors: the per-lane byte offset (voffset) is fixed for the
+  // whole K loop and the K-step advance is a scalar (soffset), so a K step costs no VALU address arithmetic at all
+  // (measured before: ~120 VALU per wave per K step for the 64-bit pointer selects, which bounded the kernel).
+  // Rows / columns past the edge get voffset 0x80000000: out of the descriptor's range -> the DMA writes zeros.
+  constexpr int OOB = (int)0x80000000;
+  int voffA[4], voffB[4];
+  __amdgpu_buffer_rsrc_t rsrcA, rsrcB;
+  const bool use_srd = GLDS && GATHER == 0 && p.use_srd;
+  if constexpr (GLDS && GATHER == 0) {
+    rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+    rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (!A_KM) {
+        const int m = m0 + rowi[i];
+        voffA[i] = m < p.M ? (int)(((long)m * p.lda + kc * 8) * 2) : OOB;
+      } else {
+        const int col = m0 + cci[i] * 8;
+        voffA[i] = col < p.M ? (int)(((long)krowi[i] * p.lda + col) * 2) : OOB;
+      }
+      if constexpr (!B_KM) {
+        const int n = n0 + rowi[i];
+        voffB[i] = n < p.N ? (int)(((long)n * p.ldb + kc * 8) * 2) : OOB;
+      } else {
+        const int col = n0 + cci[i] * 8;
+        voffB[i] = col < p.N ? (int)(((long)krowi[i] * p.ldb + col) * 2) : OOB;
+      }
+    }
+  }
+
   // GLDS: issue the 8 LDS-DMA loads of a K step into LDS stage `stage`
   auto stage_glds = [&](int stage, int k0) {
     unsigned char* sa = smem + stage * STAGE_BYTES + wave * 4096;
     unsigned char* sb = sa + TILE_BYTES;
+    if constexpr (GLDS && GATHER == 0) {
+      if (use_srd && k0 + TBK <= kend) {  // full K step: descriptor path (a partial last step takes the pointer path)
+        const int soffA = A_KM ? (int)((long)k0 * p.lda * 2) : k0 * 2;
+        const int soffB = B_KM ? (int)((long)k0 * p.ldb * 2) : k0 * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)(sa + i * 1024), 16, voffA[i], soffA, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(sb + i * 1024), 16, voffB[i], soffB, 0, 0);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       __builtin_amdgcn_global_load_lds((gptr_t)src_a(i, k0), (lptr_t)(sa + i * 1024), 16, 0, 0);
@@ -290,33 +333,46 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   }
   __syncthreads();  // (hipcc drains the outstanding LDS-DMA with vmcnt(0) ahead of the barrier)
 
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
+  // One K step on the compile-time LDS stage ST (the loop is unrolled by two so every fragment address is a loop-
+  // invariant VGPR plus an immediate): issue all 16 fragment reads, then the LDS-DMA of the next tile into the other
+  // stage (it must not sit in front of the reads in the memory queues), then the 32 MFMAs at raised priority.
+  // Before this form the compiler recomputed ~100 VALU of addresses per step and drained lgkmcnt(0) three times.
+  auto kstep = [&](auto st_c, int kt) {
+    constexpr int ST = decltype(st_c)::value;
     const bool more = kt + 1 < nk;
-    if (more) {
-      if constexpr (GLDS) stage_glds(cur ^ 1, kbeg + (kt + 1) * TBK);
-      else load_regs(kbeg + (kt + 1) * TBK);
-    }
-    const unsigned char* sa = smem + cur * STAGE_BYTES;
+    const unsigned char* sa = smem + ST * STAGE_BYTES;
     const unsigned char* sb = sa + TILE_BYTES;
+    bf16x8 fa[2][4], fb[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KM>(sa, wm * 64 + i * 16, kk, lane);
+      for (int i = 0; i < 4; ++i) fa[kk][i] = read_frag<A_KM>(sa, wm * 64 + i * 16, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KM>(sb, wn * 64 + j * 16, kk, lane);
+      for (int j = 0; j < 4; ++j) fb[kk][j] = read_frag<B_KM>(sb, wn * 64 + j * 16, kk, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      if constexpr (GLDS) stage_glds(ST ^ 1, kbeg + (kt + 1) * TBK);
+      else load_regs(kbeg + (kt + 1) * TBK);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
     if constexpr (!GLDS) {
-      if (more) store_regs(cur ^ 1);
+      if (more) store_regs(ST ^ 1);
     }
     __syncthreads();
-    cur ^= 1;
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
   }
 
   // ---- epilogue: lane holds C[m = ..+(lane&15)][n = ..+4*(lane>>4)+r]
@@ -326,6 +382,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + wn * 64 + j * 16 + 4 * g;
     bias4[j] = (p.bias && p.split_k <= 1 && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // fast path: plain bf16 store (+ bias) — most launches (dgrads, convolutions) — without the option branches
+  if (p.split_k <= 1 && !p.C2 && p.act == MMSA_ACT_NONE && !p.mul && !p.add && !p.out_f32) {
+    bf16* Cb = (bf16*)p.C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + r16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * g;
+        if (n < p.N) Vec4<bf16>::store(Cb + (long)m * p.ldc + n, acc[i][j] + bias4[j]);
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -453,6 +524,19 @@ static int gemm_bf16_launch_inner(const GemmParams& pin, hipStream_t st) {
   if (p.split_k < 1) p.split_k = 1;
   p.zero_page = mmsa_zero_page();
   if (!p.zero_page) return MMSA_ERR_LAUNCH;
+  {
+    // byte extent of each operand view; the descriptor path needs every offset to fit a positive 32-bit int
+    const long ea = p.a_kmajor ? ((long)(p.K - 1) * p.lda + p.M) * 2 : ((long)(p.M - 1) * p.lda + p.K) * 2;
+    const long eb = p.b_kmajor ? ((long)(p.K - 1) * p.ldb + p.N) * 2 : ((long)(p.N - 1) * p.ldb + p.K) * 2;
+    const char* off = getenv("MMSA_GEMM_NO_SRD");
+    p.use_srd = (p.gather == 0 && ea < 0x7FFFFFF0L && eb < 0x7FFFFFF0L && !(off && atoi(off))) ? 1 : 0;
+    p.a_bytes = p.use_srd ? (unsigned)ea : 0;
+    p.b_bytes = p.use_srd ? (unsigned)eb : 0;
+    // timing-only diagnostic (results are wrong): zero-record descriptors make the range check drop every staging
+    // load while the instruction stream, waits and barriers stay (cdna guide §7) — prices the memory side of the loop.
+    if (const char* nl = getenv("MMSA_GEMM_DBG_NOLOAD"))
+      if (atoi(nl) && p.use_srd) { p.a_bytes = 0; p.b_bytes = 0; }
+  }
   if (p.gather == 0) {
     if (!p.a_kmajor && !p.b_kmajor) return launch_variant<false, false, 0>(p, st);
     if (!p.a_kmajor && p.b_kmajor) return launch_variant<false, true, 0>(p, st);

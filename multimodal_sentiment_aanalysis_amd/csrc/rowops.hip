@@ -203,12 +203,22 @@ int layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, c
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long ldx, float* __restrict__ part,
                                                              int M, int N, int rows_per_chunk) {
-  const int col = (blockIdx.y * 256 + threadIdx.x) * 4;
-  if (col >= N) return;
+  // 256 threads = 16 column threads (4 columns each: a 64-column group per block) x 16 row lanes, so a narrow matrix
+  // (N = 768: 12 column groups) still launches chunks x 12 workgroups instead of `chunks`.
+  __shared__ f32x4 red[256];
+  const int ct = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int col = (blockIdx.y * 16 + ct) * 4;
   const int r0 = blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
   f32x4 a = {0, 0, 0, 0};
-  for (int r = r0; r < r1; ++r) a += Vec4<T>::load(x + (long)r * ldx + col);
-  *(f32x4*)(part + (long)blockIdx.x * N + col) = a;
+  if (col < N)
+    for (int r = r0 + rl; r < r1; r += 16) a += Vec4<T>::load(x + (long)r * ldx + col);
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (rl == 0 && col < N) {
+#pragma unroll
+    for (int j = 1; j < 16; ++j) a += red[j * 16 + ct];
+    *(f32x4*)(part + (long)blockIdx.x * N + col) = a;
+  }
 }
 
 #define COLSUM_CHUNKS 128
@@ -235,7 +245,7 @@ int colsum(int dtype, const void* x, long ldx, float* out, int accumulate, float
   }
   const int rpc = cdiv(M, COLSUM_CHUNKS);
   const int chunks = cdiv(M, rpc);
-  dim3 grid(chunks, cdiv(N, 1024));
+  dim3 grid(chunks, cdiv(N, 64));
   if (dtype == MMSA_BF16)
     hipLaunchKernelGGL(colsum_partial_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, ldx, ws, M, N, rpc);
   else
