@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 }
 
 // backward pass 1: dz = dy * act'(z); partial sums of dz and dz * xhat.  ReLU mask comes from the saved output y
-// (y > 0 <=> z > 0, also with a residual); GELU (no residual in the reference) recomputes z from x.
+// (y > 0 <=> z > 0, also with a residual) or, when y == null (no residual), is recomputed from x with the forward's own
+// expression x*sc + sh, which saves one of the three streamed reads; GELU (no residual in the reference) recomputes z.
 template <typename T>
 __device__ __forceinline__ f32x4 bn_dz(f32x4 dy, f32x4 xh, f32x4 g, f32x4 b, f32x4 yv, int act) {
   f32x4 dz = dy;
@@ -149,10 +150,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
   if (col < C) {
     const f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
     const f32x4 g = *(const f32x4*)(gamma + col), b = *(const f32x4*)(beta + col);
+    const f32x4 sc = is * g, sh = b - mu * sc;  // as bn_apply_kernel: the ReLU mask without a saved output (y == null)
     for (int r = r0 + rl; r < r1; r += rlanes) {
-      const f32x4 xh = (Vec4<T>::load(x + (long)r * C + col) - mu) * is;
+      const f32x4 xr = Vec4<T>::load(x + (long)r * C + col);
+      const f32x4 xh = (xr - mu) * is;
       f32x4 yv = {0, 0, 0, 0};
-      if (act == MMSA_ACT_RELU) yv = Vec4<T>::load(y + (long)r * C + col);
+      if (act == MMSA_ACT_RELU) yv = y ? Vec4<T>::load(y + (long)r * C + col) : xr * sc + sh;
       const f32x4 dz = bn_dz<T>(Vec4<T>::load(dy + (long)r * C + col), xh, g, b, yv, act);
       s += dz;
       q += dz * xh;
@@ -221,10 +224,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     mg = *(const f32x4*)(sums + C + col) * invM;
   }
   const f32x4 gi = g * is;
+  const f32x4 sc = is * g, sh = b - mu * sc;
   for (long r = (long)blockIdx.x * rlanes + rl; r < M; r += (long)gridDim.x * rlanes) {
-    const f32x4 xh = (Vec4<T>::load(x + r * C + col) - mu) * is;
+    const f32x4 xr = Vec4<T>::load(x + r * C + col);
+    const f32x4 xh = (xr - mu) * is;
     f32x4 yv = {0, 0, 0, 0};
-    if (act == MMSA_ACT_RELU) yv = Vec4<T>::load(y + r * C + col);
+    if (act == MMSA_ACT_RELU) yv = y ? Vec4<T>::load(y + r * C + col) : xr * sc + sh;
     const f32x4 dz = bn_dz<T>(Vec4<T>::load(dy + r * C + col), xh, g, b, yv, act);
     if (dres) Vec4<T>::store(dres + r * C + col, dz);
     Vec4<T>::store(dx + r * C + col, gi * (dz - mb - xh * mg));
@@ -290,7 +295,6 @@ int bn_backward(int dtype, const void* dy, const void* x, const void* y, const f
                 const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
                 float* ws, int M, int C, int act, int training, hipStream_t st) {
   if (C % 4 || M <= 0) return MMSA_ERR_ARG;
-  if (act == MMSA_ACT_RELU && !y) return MMSA_ERR_ARG;
   if (dtype == MMSA_BF16)
     return bn_backward_t<bf16>((const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, gamma, beta, (bf16*)dx,
                                (bf16*)dres, dgamma, dbeta, accumulate, ws, M, C, act, training, st);

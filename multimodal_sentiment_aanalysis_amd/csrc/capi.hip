@@ -24,8 +24,9 @@ static GemmParams to_params(const mmsa_gemm_desc* d) {
   g.fd_cper = make_fastdiv(s.cper > 0 ? s.cper : 1);
   p.bias = d->bias; p.C2 = d->C2; p.ldc2 = d->ldc2; p.act = d->act;
   p.mul = d->mul; p.ldmul = d->ldmul; p.add = d->add; p.ldadd = d->ldadd;
-  p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.split_k = d->split_k; p.ws = d->ws;
+  p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.split_k = d->split_k; p.ws = d->ws; p.ws_bytes = 0;
   p.zero_page = nullptr;
+  p.a_bytes = p.b_bytes = 0; p.use_srd = 0;
   return p;
 }
 

@@ -69,12 +69,22 @@ struct Eng {
     const char* v = getenv("MMSA_BF16_SIMT");  // read per call so a test can toggle it inside one process
     return v && atoi(v) != 0;
   }
+  static bool v1_only() {
+    const char* v = getenv("MMSA_GEMM_V1");
+    return v && atoi(v) != 0;
+  }
   int gemm(const GemmParams& pin) const {
     if (dtype != MMSA_BF16) return gemm_f32_launch(pin, st);
     if (force_simt()) return gemm_bf16_simt_launch(pin, st);
     // Few-tile, deep-K launches (stage-3/4 convolutions: 100-200 tiles of 128x128 for 256 CUs x 2 slots) get a split
     // over K so that the machine is filled; the slab reducer applies the epilogue.
     GemmParams p = pin;
+    if (splitk_ws && !(p.N % 4) && gemm2_eligible(p) && !v1_only()) {  // the persistent kernel plans its own K split
+      if (p.split_k < 1) p.split_k = 1;
+      p.ws = splitk_ws;
+      p.ws_bytes = (long)splitk_bytes;
+      return gemm_bf16_launch(p, st);
+    }
     if (p.split_k <= 1 && splitk_ws && !(p.N % 4)) {
       const long tiles = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
       if (tiles <= 200 && p.K >= 1024) {

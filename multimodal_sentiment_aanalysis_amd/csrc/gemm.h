@@ -56,6 +56,7 @@ struct GemmParams {
   // split-K: when split_k > 1 raw fp32 partials go to ws[split][M][N] and a second kernel reduces them into C
   int split_k;
   float* ws;
+  long ws_bytes;          // capacity of ws (0: exactly split_k slabs); lets the persistent kernel pick its own K split
   const void* zero_page;  // >= 64 bytes of zeros in device memory (source for padded taps)
   // filled by the MFMA launcher: byte extents of the A / B views for the buffer-descriptor staging path
   unsigned a_bytes, b_bytes;
@@ -63,6 +64,8 @@ struct GemmParams {
 };
 
 int gemm_bf16_launch(const GemmParams& p, hipStream_t st);
+bool gemm2_eligible(const GemmParams& p);
+int gemm2_launch(const GemmParams& p, size_t ws_bytes_avail, hipStream_t st);
 int gemm_f32_launch(const GemmParams& p, hipStream_t st);
 size_t gemm_splitk_ws_bytes(int M, int N, int split_k);
 const void* mmsa_zero_page();

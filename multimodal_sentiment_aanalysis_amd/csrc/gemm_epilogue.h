@@ -85,15 +85,44 @@ __device__ __forceinline__ void gemm_epilogue1(const GemmParams& p, int m, int n
   }
 }
 
-// Split-K second pass: sums the fp32 partial slabs and applies the epilogue.
+// Split-K second pass: sums the fp32 partial slabs and applies the epilogue. 256 threads = (256 / L) float4 outputs x
+// L slab lanes: lane l adds slabs l, l+L, ... in order, then the lanes are added in order through LDS (fixed
+// summation tree -> bitwise reproducible). L > 1 is picked by the launcher when the output is so small that one
+// thread per output would leave the chip empty and walk hundreds of slabs serially (stage-1 weight gradients:
+// 64x64 outputs x 256 slabs took 75 us on 4 workgroups).
 template <typename T>
-__global__ void gemm_splitk_reduce_kernel(GemmParams p) {
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p, int L) {
+  __shared__ f32x4 red[256];
   const long total4 = (long)p.M * p.N / 4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const long e = i * 4;
-    const int m = (int)(e / p.N), n = (int)(e - (long)m * p.N);
+  const int opb = 256 / L;
+  const int l = threadIdx.x / opb, o = threadIdx.x - l * opb;
+  const long slab = (long)p.M * p.N;
+  for (long base = (long)blockIdx.x * opb; base < total4; base += (long)gridDim.x * opb) {
+    const long i = base + o;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < p.split_k; ++s) v += *(const f32x4*)(p.ws + (long)s * p.M * p.N + e);
-    gemm_epilogue4<T>(p, m, n, v);
+    if (i < total4)
+      for (int s = l; s < p.split_k; s += L) v += *(const f32x4*)(p.ws + (long)s * slab + i * 4);
+    if (L > 1) {
+      __syncthreads();
+      red[threadIdx.x] = v;
+      __syncthreads();
+      if (l == 0)
+        for (int j = 1; j < L; ++j) v += red[j * opb + o];
+    }
+    if (l == 0 && i < total4) {
+      const long e = i * 4;
+      const int m = (int)(e / p.N), n = (int)(e - (long)m * p.N);
+      gemm_epilogue4<T>(p, m, n, v);
+    }
   }
+}
+
+template <typename T>
+static inline void launch_splitk_reduce(const GemmParams& p, hipStream_t st) {
+  const long total4 = (long)p.M * p.N / 4;
+  int L = 1;
+  while (L < 64 && L * 2 <= p.split_k && (total4 * L + 255) / 256 < 512) L *= 2;
+  long blocks = (total4 * L + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel<T>, dim3((int)blocks), dim3(256), 0, st, p, L);
 }

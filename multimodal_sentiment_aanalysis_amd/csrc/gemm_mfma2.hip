@@ -1,0 +1,593 @@
+// bf16 MFMA GEMM for gfx950, second generation: persistent workgroups, 3-stage LDS-DMA ring, counted waits.
+//
+// Why: the 128x128 / 2-stage kernel (gemm_mfma.hip) drains every LDS-DMA at each K step (`vmcnt(0)` + barrier), so a
+// step can never be shorter than one memory round trip: ~550 TF/s on the BERT shapes (K = 768: 12 steps), and on the
+// ResNet shapes with K = 64..576 (1-9 steps per tile) the load of a tile is not overlapped with anything but the
+// co-resident workgroup.
+// Here one 512-thread workgroup per CU (8 waves = 4(M) x 2(N), 64 x (BN/2) outputs per wave, BN = 64 / 96 / 128)
+// walks a list of work items (tile x K-split) and treats the K steps of ALL its items as one stream:
+//   * 3 LDS stages of 48 KiB (A 256x64 + B 128x64 bf16); the DMA of step u+2 is issued during step u, and the wait at
+//     the top of a step is a COUNTED `s_waitcnt vmcnt(N)` that leaves the newer step's DMA (and the stores of the last
+//     two epilogues) in flight, followed by ONE raw `s_barrier` (never `__syncthreads()`, whose fence would drain
+//     the DMA queue) — CDNA4 guide 'Pipelining across barriers';
+//   * the prefetch runs across item boundaries, so the epilogue stores of tile t overlap the loads of tile t+1 and a
+//     K = 64 convolution streams at the HBM rate instead of the load latency;
+//   * epilogue stores go through a buffer descriptor (out-of-range lanes are dropped by the hardware, no branches),
+//     so the number of vector-memory operations per epilogue is a compile-time constant and the counted waits stay
+//     exact. Epilogues that read memory (bias / residual / gelu' operands) drain once per tile instead.
+//   * BN = 96 exists because BERT-base has N in {768, 2304, 3072} at M = 8192: 32 row tiles x N/96 column tiles is an
+//     exact multiple of the 256 CUs for all three (128-wide tiles leave a quarter of the chip idle on the last round).
+// LDS images, swizzles and fragment reads are those of gemm_tile.h (shared with the first-generation kernel).
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "gemm.h"
+#include "gemm_epilogue.h"
+#include "gemm_tile.h"
+
+#define G2_BM 256
+#define G2_BK 64
+#define G2_A_BYTES 32768
+#define G2_B_BYTES 16384
+#define G2_STAGE (G2_A_BYTES + G2_B_BYTES)
+#define G2_LDS (3 * G2_STAGE)
+
+struct G2Sched {
+  int ntm, ntn, ntiles;  // tile grid
+  int split_k, per;      // K splits; K steps per split
+  int nsteps;            // K / 64
+  int items;             // ntiles * split_k; item = split * ntiles + tile (tiles of one K slice are neighbours)
+  int fast;              // epilogue is a plain store (no memory reads): exact store counting
+  FastDiv fd_ntiles, fd_ntn;
+  unsigned c_bytes;      // byte extent of the output view (C, or the split-K slabs)
+  int dbg;               // timing-only ablations (MMSA_G2_DBG bitmask; results are wrong): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no epilogue
+};
+
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt = simm16[15:14|3:0], expcnt [6:4] = 7 and lgkmcnt [11:8] = 15 mean
+// "do not wait"). The builtin, not inline asm: hipcc's own wait-insertion pass then knows which vector-memory
+// operations have completed (with asm it kept a stale "bias load pending" state across the loop back-edge and put a
+// vmcnt(0) in front of a fragment read of every K step).
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);
+}
+
+// s_waitcnt lgkmcnt(N) only (vmcnt = 63, expcnt = 7: no wait); lgkmcnt is 4 bits
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+  static_assert(N >= 0 && N < 16, "lgkmcnt is 4 bits");
+  __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));
+}
+
+// Fragment reads as inline asm: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16
+// builtin while an LDS-DMA is outstanding (it cannot prove the transpose read does not alias the DMA's LDS write),
+// which drained the 3-stage ring twice per K step in every k-major variant. The asm forms carry no memory operand;
+// ordering against the DMA is by the counted vmcnt + barrier, and their results are awaited with explicit
+// lgkmcnt waits (each followed by sched_barrier(0), CDNA4 guide rule 18).
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_rd128(unsigned addr) {
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(IMM));
+  return r;
+}
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_rd_tr(unsigned addr) {  // k rows kb..kb+3 (lo) and kb+4..kb+7 (hi = +1024 B)
+  typedef __attribute__((ext_vector_type(2))) int i32x2_;
+  i32x2_ lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(IMM));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(IMM + 1024));
+  typedef __attribute__((ext_vector_type(4))) int i32x4_;
+  i32x4_ r = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int NJ, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) {
+  // The body is compiled in the device pass only: hipcc's HOST pass (ROCm 7.2) silently fails to instantiate this
+  // template when it sees the body (no diagnostic, the launch stub stays an undefined symbol of the .so).
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BN = NJ * 32;
+  constexpr int NLB = (NJ == 2 && !B_KM) ? 1 : 2;  // B LDS-DMA pieces per wave per step
+  constexpr int NL = 4 + NLB;                      // LDS-DMA instructions per wave per step
+  // store instructions per wave per plain epilogue, in units of 2 NJ: bf16 output = 1 unit (16 B per lane, row tiles
+  // paired), fp32 output / split-K slabs = 2 units. The counted waits need the exact number.
+  constexpr int NSU = 2 * NJ;
+  constexpr int OOB = (int)0x80000000;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- logical workgroup id: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of items
+  const int G = gridDim.x;
+  int lb;
+  {
+    const int q = G >> 3, r = G & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  if (lb >= s.items) return;
+
+  // ---- item decode (all scalar)
+  struct Item { int m0, n0, kb, nk, sp; };
+  auto decode = [&](int item) __attribute__((always_inline)) -> Item {
+    Item it;
+    const int sp = (int)fd_div((uint32_t)item, s.fd_ntiles);
+    const int tile = item - sp * s.ntiles;
+    const int tm = (int)fd_div((uint32_t)tile, s.fd_ntn);
+    const int tn = tile - tm * s.ntn;
+    it.m0 = tm * G2_BM; it.n0 = tn * BN; it.sp = sp;
+    it.kb = sp * s.per;
+    it.nk = min(s.per, s.nsteps - it.kb);
+    return it;
+  };
+  int total = 0;
+  if (s.split_k == 1) total = ((s.items - lb + G - 1) / G) * s.nsteps;
+  else
+    for (int it = lb; it < s.items; it += G) total += decode(it).nk;
+
+  // ---- per-lane staging map: relative byte offsets inside a tile (the tile origin and the K advance are scalar)
+  int relA[4], rcA[4], relB[NLB], rcB[NLB];  // rc = row (k-contiguous) or first column (k-major) inside the tile
+  {
+    const int kc = (lane & 7) ^ (lane >> 3);
+    const int pc = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pi = wave * 4 + i;
+      if constexpr (!A_KM) {
+        rcA[i] = pi * 8 + (lane >> 3);
+        relA[i] = (int)(((long)rcA[i] * p.lda + kc * 8) * 2);
+      } else {  // two [64][128] halves; piece = 4 k-rows of one half
+        const int half = pi >> 4, krow = 4 * (pi & 15) + (lane >> 4);
+        const int cc = ((((pc >> 1) ^ kmajor_swz(krow)) << 1) | (pc & 1));
+        rcA[i] = half * 128 + cc * 8;
+        relA[i] = (int)(((long)krow * p.lda + rcA[i]) * 2);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int pi = wave * NLB + i;
+      if constexpr (!B_KM) {
+        rcB[i] = pi * 8 + (lane >> 3);
+        relB[i] = (int)(((long)rcB[i] * p.ldb + kc * 8) * 2);
+      } else {
+        const int krow = 4 * pi + (lane >> 4);
+        const int cc = ((((pc >> 1) ^ kmajor_swz(krow)) << 1) | (pc & 1));
+        rcB[i] = cc * 8;
+        relB[i] = (int)(((long)krow * p.ldb + rcB[i]) * 2);
+      }
+    }
+  }
+  __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrcC =
+      __builtin_amdgcn_make_buffer_rsrc(s.split_k > 1 ? (void*)p.ws : p.C, 0, s.c_bytes, 0x00020000);
+
+  // ---- loader cursor
+  int l_item = lb, l_kt = 0;
+  Item L = decode(l_item);
+  int voffA[4], voffB[NLB];
+  auto loader_setup = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) voffA[i] = (L.m0 + rcA[i] < p.M) ? relA[i] : OOB;
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) voffB[i] = (rcB[i] < BN && L.n0 + rcB[i] < p.N) ? relB[i] : OOB;
+  };
+  loader_setup();
+  // LDS-DMA of the loader cursor's K step into `stage`: dma_begin (scalar offsets), NL x dma_piece, dma_advance
+  int d_soffA = 0, d_soffB = 0;
+  auto dma_begin = [&]() __attribute__((always_inline)) {
+    const int k0 = (L.kb + l_kt) * G2_BK;
+    d_soffA = A_KM ? (int)(((long)k0 * p.lda + L.m0) * 2) : (int)(((long)L.m0 * p.lda + k0) * 2);
+    d_soffB = B_KM ? (int)(((long)k0 * p.ldb + L.n0) * 2) : (int)(((long)L.n0 * p.ldb + k0) * 2);
+  };
+  auto dma_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
+    constexpr int pc = decltype(pc_c)::value;
+    if constexpr (pc < 4) {
+      unsigned char* sa = smem + stage * G2_STAGE + wave * 4096 + pc * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)sa, 16, voffA[pc], d_soffA, 0, 0);
+    } else if constexpr (pc < NL) {
+      unsigned char* sb = smem + stage * G2_STAGE + G2_A_BYTES + wave * (NLB * 1024) + (pc - 4) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)sb, 16, voffB[pc - 4], d_soffB, 0, 0);
+    }
+  };
+  auto dma_advance = [&]() __attribute__((always_inline)) {
+    if (++l_kt == L.nk) {
+      l_kt = 0;
+      l_item += G;
+      if (l_item < s.items) {
+        L = decode(l_item);
+        loader_setup();
+      }
+    }
+  };
+  auto issue = [&](int stage) __attribute__((always_inline)) {
+    dma_begin();
+    dma_piece(stage, std::integral_constant<int, 0>{});
+    dma_piece(stage, std::integral_constant<int, 1>{});
+    dma_piece(stage, std::integral_constant<int, 2>{});
+    dma_piece(stage, std::integral_constant<int, 3>{});
+    dma_piece(stage, std::integral_constant<int, 4>{});
+    dma_piece(stage, std::integral_constant<int, 5>{});
+    dma_advance();
+  };
+
+  // ---- compute cursor
+  int c_item = lb, c_kt = 0;
+  Item C = decode(c_item);
+  f32x4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, g4 = lane >> 4;
+  auto epilogue = [&]() __attribute__((always_inline)) -> int {  // returns the store units it issued (0: it drained the queue)
+    const int mb = C.m0 + wm * 64 + r16, nb = C.n0 + wn * (NJ * 16) + 4 * g4;
+    if (s.split_k > 1) {  // raw fp32 partials -> slab sp
+      const long slab = (long)C.sp * p.M * p.N;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mb + i * 16;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int n = nb + j * 16;
+          const int vo = (m < p.M && n < p.N) ? (int)((slab + (long)m * p.N + n) * 4) : OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, acc[i][j]), rsrcC, vo, 0, 0);
+        }
+      }
+      return 2;
+    }
+    if (s.fast) {
+      if (p.out_f32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = mb + i * 16;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int n = nb + j * 16;
+            const int vo = (m < p.M && n < p.N) ? (int)(((long)m * p.ldc + n) * 4) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, acc[i][j]), rsrcC, vo, 0, 0);
+          }
+        }
+      } else {
+        // bf16: pair the row tiles (i, i+1) and exchange 4-column groups between neighbouring lane rows
+        // (v_permlane16_swap: g <-> g^1), so every lane stores 8 consecutive columns = 16 bytes: half the store
+        // instructions of the 8-byte form (the epilogue is store-ISSUE bound: CDNA4 guide T21).
+        // even g: tile i, columns 4g..4g+7; odd g: tile i+1, columns 4(g-1)..4(g-1)+7
+        const int mrow = mb + ((g4 & 1) << 4), ncol = C.n0 + wn * (NJ * 16) + ((g4 >> 1) << 3);
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+          const int m = mrow + i * 16;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int n = ncol + j * 16;
+            const f32x4 x = acc[i][j], y = acc[i + 1][j];
+            const bf16x4 xb = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
+            const bf16x4 yb = {(bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
+            const i32x2 xi = __builtin_bit_cast(i32x2, xb), yi = __builtin_bit_cast(i32x2, yb);
+            const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)xi[0], (unsigned)yi[0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)xi[1], (unsigned)yi[1], false, false);
+            const i32x4 d = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+            const int vo = (m < p.M && n < p.N) ? (int)(((long)m * p.ldc + n) * 2) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(d, rsrcC, vo, 0, 0);
+          }
+        }
+      }
+      return p.out_f32 ? 2 : 1;
+    }
+    // general epilogue (reads bias / side operands): branches + loads, then a full drain so the counted waits of the
+    // following steps see an empty queue
+    f32x4 bias4[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = nb + j * 16;
+      bias4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + i * 16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n = nb + j * 16;
+        if (n < p.N) gemm_epilogue4b<bf16>(p, m, n, acc[i][j], bias4[j]);
+      }
+    }
+    wait_vm<0>();
+    return 0;
+  };
+
+  // ---- main loop. One iteration = one K step (64 deep) of the stream, in two halves of 32:
+  //   first half : issue the fragment reads of the step's second half, run the MFMAs of its first half
+  //   mid-step   : lgkmcnt(0) (all reads of this stage are done) + counted vmcnt (next step's DMA has landed) + barrier
+  //   second half: issue the fragment reads of the NEXT step's first half and the DMA that refills the stage just
+  //                freed (step u+3), run the MFMAs of the second half, then the epilogue if the item ends here.
+  // So every LDS read is issued one half-step ahead of the MFMAs that consume it (all 8 waves leave the barrier
+  // together: without this the LDS burst of a step sat in front of its MFMAs, 1/3 of the step), and three steps of
+  // DMA are in flight. Stage of step u = u mod 3 (run-time scalar added to loop-invariant per-lane addresses).
+  // per-lane fragment addresses inside a stage (loop invariant). k-contiguous: one per kk (row tiles i are +2048 B);
+  // k-major: one per row tile (kk is +8192 B, the upper 4 k rows +1024 B): the XOR swizzles depend on exactly those.
+  constexpr int NFA = A_KM ? 4 : 2, NFB = B_KM ? NJ : 2;
+  unsigned offA[NFA], offB[NFB];
+  {
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int q = r16 >> 2, pp = r16 & 3;
+    if constexpr (!A_KM) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) offA[kk] = lds0 + kc_off(wm * 64 + r16, kk * 4 + g4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = (wm & 1) * 64 + i * 16 + 4 * pp;
+        offA[i] = lds0 + (wm >> 1) * 16384 + km_off(8 * g4 + q, col >> 3) + ((pp & 1) << 3);
+      }
+    }
+    if constexpr (!B_KM) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) offB[kk] = lds0 + G2_A_BYTES + kc_off(wn * (NJ * 16) + r16, kk * 4 + g4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = wn * (NJ * 16) + j * 16 + 4 * pp;
+        offB[j] = lds0 + G2_A_BYTES + km_off(8 * g4 + q, col >> 3) + ((pp & 1) << 3);
+      }
+    }
+  }
+  constexpr int RD_HALF = (A_KM ? 8 : 4) + (B_KM ? 2 * NJ : NJ);  // LDS instructions of one read_half
+  auto read_half = [&](auto kk_c, int stage, bf16x8(&fa)[4], bf16x8(&fb)[NJ]) __attribute__((always_inline)) {
+    constexpr int kk = decltype(kk_c)::value;
+    const unsigned so = (unsigned)(stage * G2_STAGE);
+    if constexpr (!A_KM) {
+      const unsigned a = offA[kk] + so;
+      fa[0] = lds_rd128<0>(a); fa[1] = lds_rd128<2048>(a); fa[2] = lds_rd128<4096>(a); fa[3] = lds_rd128<6144>(a);
+    } else {
+      fa[0] = lds_rd_tr<kk * 8192>(offA[0] + so); fa[1] = lds_rd_tr<kk * 8192>(offA[1] + so);
+      fa[2] = lds_rd_tr<kk * 8192>(offA[2] + so); fa[3] = lds_rd_tr<kk * 8192>(offA[3] + so);
+    }
+    if constexpr (!B_KM) {
+      const unsigned b = offB[kk] + so;
+      fb[0] = lds_rd128<0>(b); fb[1] = lds_rd128<2048>(b);
+      if constexpr (NJ > 2) fb[2] = lds_rd128<4096>(b);
+      if constexpr (NJ > 3) fb[3] = lds_rd128<6144>(b);
+    } else {
+      fb[0] = lds_rd_tr<kk * 8192>(offB[0] + so); fb[1] = lds_rd_tr<kk * 8192>(offB[1] + so);
+      if constexpr (NJ > 2) fb[2] = lds_rd_tr<kk * 8192>(offB[2] + so);
+      if constexpr (NJ > 3) fb[3] = lds_rd_tr<kk * 8192>(offB[3] + so);
+    }
+  };
+  auto mma_half = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[NJ]) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // the same 4 x NJ MFMAs with the NL LDS-DMA instructions of one K step spread between them (one after every second
+  // MFMA): issued in a burst right after the barrier by all 8 waves they queue in the address unit and every wave's
+  // MFMA stream stands still behind them
+  auto mma_half_dma = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[NJ], int stage) __attribute__((always_inline)) {
+    dma_begin();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    auto one = [&](auto idx_c) __attribute__((always_inline)) {
+      constexpr int idx = decltype(idx_c)::value;
+      constexpr int i = idx / NJ, j = idx % NJ;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      if constexpr ((idx & 1) == 1 && idx / 2 < NL) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_piece(stage, std::integral_constant<int, idx / 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+    one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+    one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+    one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+    if constexpr (NJ > 2) {
+      one(std::integral_constant<int, 8>{}); one(std::integral_constant<int, 9>{});
+      one(std::integral_constant<int, 10>{}); one(std::integral_constant<int, 11>{});
+    }
+    if constexpr (NJ > 3) {
+      one(std::integral_constant<int, 12>{}); one(std::integral_constant<int, 13>{});
+      one(std::integral_constant<int, 14>{}); one(std::integral_constant<int, 15>{});
+    }
+    if constexpr (2 * NJ < NL) {  // NJ = 2: 8 MFMAs carry 4 pieces; the B piece(s) follow
+      dma_piece(stage, std::integral_constant<int, 4>{});
+      dma_piece(stage, std::integral_constant<int, 5>{});
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    dma_advance();
+  };
+
+  // prologue: up to three steps of DMA in flight, then wait for step 0 and read its first-half fragments
+  issue(0);
+  if (total > 1) issue(1);
+  if (total > 2) issue(2);
+  if (total > 2) wait_vm<2 * NL>();
+  else if (total > 1) wait_vm<NL>();
+  else wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  bf16x8 a0[4], b0[NJ], a1[4], b1[NJ];
+  read_half(std::integral_constant<int, 0>{}, 0, a0, b0);
+  if (s.dbg & 2) read_half(std::integral_constant<int, 1>{}, 0, a1, b1);
+
+  int eu1 = 0, eu2 = 0;  // store units of the counted epilogue that ended the previous step / the one before
+  int st = 0;     // u % 3
+  for (int u = 0; u < total; ++u) {
+    if (!(s.dbg & 2)) read_half(std::integral_constant<int, 1>{}, st, a1, b1);
+    wait_lgkm<(RD_HALF < 14 ? RD_HALF : 14)>();  // first-half fragments (issued half a step ago) are in; 15 = "no wait"
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int nst = st == 2 ? 0 : st + 1;
+    wait_lgkm<0>();  // second-half fragments are in (and every read of this stage is done: it may be refilled)
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 1 < total) {
+      {  // step u+1's DMA: allow the newer step's loads + the stores of counted epilogues issued after it
+        const int code = (u + 2 < total ? 5 : 0) + eu1 + eu2;
+        switch (code) {
+          case 0: wait_vm<0>(); break;
+          case 1: wait_vm<NSU>(); break;
+          case 2: wait_vm<2 * NSU>(); break;
+          case 3: wait_vm<3 * NSU>(); break;
+          case 4: wait_vm<4 * NSU>(); break;
+          case 5: wait_vm<NL>(); break;
+          case 6: wait_vm<NL + NSU>(); break;
+          case 7: wait_vm<NL + 2 * NSU>(); break;
+          case 8: wait_vm<NL + 3 * NSU>(); break;
+          default: wait_vm<NL + 4 * NSU>(); break;
+        }
+      }
+      if (!(s.dbg & 4)) __builtin_amdgcn_s_barrier();
+      if (!(s.dbg & 2)) read_half(std::integral_constant<int, 0>{}, nst, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (u + 3 < total && !(s.dbg & 1)) mma_half_dma(a1, b1, st);
+    else mma_half(a1, b1);
+    int e = 0;
+    if (++c_kt == C.nk) {
+      if (!(s.dbg & 8)) e = epilogue();
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      c_kt = 0;
+      c_item += G;
+      if (c_item < s.items) C = decode(c_item);
+    }
+    eu2 = eu1;
+    eu1 = e;
+    st = nst;
+  }
+#endif
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------
+
+static int g2_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+bool gemm2_eligible(const GemmParams& p) {
+  if (p.gather != 0) return false;
+  if (p.K % G2_BK) return false;
+  if (p.N % 4) return false;
+  if (p.a_kmajor && (p.M % 8)) return false;
+  if (p.b_kmajor && (p.N % 8)) return false;
+  if ((p.lda % 8) || (p.ldb % 8)) return false;
+  const long ea = p.a_kmajor ? ((long)(p.K - 1) * p.lda + p.M) * 2 : ((long)(p.M - 1) * p.lda + p.K) * 2;
+  const long eb = p.b_kmajor ? ((long)(p.K - 1) * p.ldb + p.N) * 2 : ((long)(p.N - 1) * p.ldb + p.K) * 2;
+  // tile origins may start up to one tile past the last row: keep every scalar + vector offset a positive int32
+  const long slack = 2L * 256 * (p.lda > p.ldb ? p.lda : p.ldb) + 65536;
+  if (ea + slack >= 0x7FFFFFF0L || eb + slack >= 0x7FFFFFF0L) return false;
+  const long ec = ((long)(p.M - 1) * p.ldc + p.N) * (p.out_f32 ? 4 : 2);
+  if (ec >= 0x7FFFFFF0L) return false;
+  return true;
+}
+
+struct G2Plan { int nj, split; };
+
+// tile width and K split that keep the most MFMA slots busy over whole rounds of `cus` workgroups
+static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
+  const int ntm = cdiv(p.M, G2_BM), nsteps = p.K / G2_BK;
+  G2Plan best{4, 1};
+  double best_cost = 1e300;
+  for (int nj = 4; nj >= 2; --nj) {
+    const int bn = nj * 32, ntn = cdiv(p.N, bn);
+    const long tiles = (long)ntm * ntn;
+    int smax = 1;
+    if (ws_bytes_avail > 0 && p.ws) smax = nsteps / 4 < 64 ? (nsteps / 4 > 1 ? nsteps / 4 : 1) : 64;
+    for (int split = 1; split <= smax; ++split) {
+      const int per = cdiv(nsteps, split);
+      if (split > 1 && (per < 4 || (long)(split - 1) * per >= nsteps)) continue;
+      if (split > 1 && (size_t)split * p.M * p.N * sizeof(float) > ws_bytes_avail) continue;
+      const long items = tiles * split;
+      const long rounds = (items + cus - 1) / cus;
+      // cost ~ rounds x (steps per item x MFMA work of a tile + fixed item overhead) + slab traffic
+      // unit = 128 cycles (~53 ns): a K step of a 256 x 32 nj tile is nj units of MFMA work when MFMA-bound
+      double cost = (double)rounds * (per * (double)nj + 3.0);
+      if (split > 1) cost += 8.0 * split * (double)p.M * p.N / 4e12 / 53e-9 + 56.0;  // slab write + read, reduce launch
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = G2Plan{nj, split}; }
+    }
+  }
+  return best;
+}
+
+template <int NJ, bool A_KM, bool B_KM>
+static int g2_launch_t(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<NJ, A_KM, B_KM>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm2_kernel<NJ, A_KM, B_KM>), dim3(grid), dim3(512), G2_LDS, st, p, s);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+template <int NJ>
+static int g2_launch_nj(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
+  if (!p.a_kmajor && !p.b_kmajor) return g2_launch_t<NJ, false, false>(p, s, grid, st);
+  if (!p.a_kmajor && p.b_kmajor) return g2_launch_t<NJ, false, true>(p, s, grid, st);
+  if (p.a_kmajor && p.b_kmajor) return g2_launch_t<NJ, true, true>(p, s, grid, st);
+  return g2_launch_t<NJ, true, false>(p, s, grid, st);
+}
+
+// p.split_k on entry: 1 = no split wanted; > 1 = upper bound chosen by the caller (needs p.ws with room for it)
+int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
+  GemmParams p = pin;
+  const int cus = g2_num_cus();
+  if (p.split_k < 1) p.split_k = 1;
+  if (p.split_k > 1 && !p.ws) return MMSA_ERR_ARG;
+  G2Plan plan = g2_plan(p, cus, ws_bytes_avail);
+  if (const char* f = getenv("MMSA_G2_NJ")) { const int v = atoi(f); if (v >= 2 && v <= 4) plan.nj = v; }
+  const long slab_bytes = (long)plan.split * p.M * p.N * 4;
+  if (plan.split > 1 && slab_bytes >= 0x7FFFFFF0L) plan.split = 1;
+  G2Sched s;
+  const int bn = plan.nj * 32;
+  s.ntm = cdiv(p.M, G2_BM); s.ntn = cdiv(p.N, bn); s.ntiles = s.ntm * s.ntn;
+  s.nsteps = p.K / G2_BK;
+  s.split_k = plan.split;
+  s.per = cdiv(s.nsteps, s.split_k);
+  s.items = s.ntiles * s.split_k;
+  s.fd_ntiles = make_fastdiv((uint32_t)s.ntiles);
+  s.fd_ntn = make_fastdiv((uint32_t)s.ntn);
+  s.fast = (!p.bias && !p.C2 && p.act == MMSA_ACT_NONE && !p.mul && !p.add && !(p.out_f32 && p.accumulate)) ? 1 : 0;
+  p.split_k = s.split_k;
+  s.dbg = 0;
+  if (const char* d = getenv("MMSA_G2_DBG")) s.dbg = atoi(d);
+  s.c_bytes = s.split_k > 1 ? (unsigned)slab_bytes : (unsigned)(((long)(p.M - 1) * p.ldc + p.N) * (p.out_f32 ? 4 : 2));
+  {
+    const long ea = p.a_kmajor ? ((long)(p.K - 1) * p.lda + p.M) * 2 : ((long)(p.M - 1) * p.lda + p.K) * 2;
+    const long eb = p.b_kmajor ? ((long)(p.K - 1) * p.ldb + p.N) * 2 : ((long)(p.N - 1) * p.ldb + p.K) * 2;
+    p.a_bytes = (unsigned)ea; p.b_bytes = (unsigned)eb;
+    // timing-only diagnostic (results are wrong): zero-record descriptors make the range check drop every staging
+    // load while the instruction stream, waits and barriers stay — prices the memory side of the loop.
+    if (const char* nl = getenv("MMSA_GEMM_DBG_NOLOAD"))
+      if (atoi(nl)) { p.a_bytes = 0; p.b_bytes = 0; }
+  }
+  const int grid = (int)(s.items < cus ? s.items : cus);
+  int rc;
+  if (plan.nj == 4) rc = g2_launch_nj<4>(p, s, grid, st);
+  else if (plan.nj == 3) rc = g2_launch_nj<3>(p, s, grid, st);
+  else rc = g2_launch_nj<2>(p, s, grid, st);
+  if (rc) return rc;
+  if (s.split_k > 1) {
+    launch_splitk_reduce<bf16>(p, st);
+    MMSA_CHECK_LAUNCH();
+  }
+  return MMSA_OK;
+}

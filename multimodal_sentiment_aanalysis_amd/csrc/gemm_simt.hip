@@ -144,10 +144,7 @@ static int simt_launch(const GemmParams& pin, hipStream_t st) {
   hipLaunchKernelGGL(gemm_simt_kernel<T>, grid, dim3(256), 0, st, p);
   MMSA_CHECK_LAUNCH();
   if (p.split_k > 1) {
-    const long total4 = (long)p.M * p.N / 4;
-    int blocks = (int)((total4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, st, p);
+    launch_splitk_reduce<T>(p, st);
     MMSA_CHECK_LAUNCH();
   }
   return MMSA_OK;

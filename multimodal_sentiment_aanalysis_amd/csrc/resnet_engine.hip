@@ -350,10 +350,10 @@ int mmsa_resnet_bwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
     RET_IF(bn_bwd(r, bd.c3, bw.c3, dOut, bw.c3.y, t1, t2, MMSA_ACT_RELU, ws.bnws));
     RET_IF(conv_wgrad(r, bd.c3, t1, bw.c2.y, r.G(bd.c3.w), acc));
     RET_IF(conv_dgrad(r, bd.c3, t1, t3, nullptr));                                   // dy2 -> t3
-    RET_IF(bn_bwd(r, bd.c2, bw.c2, t3, bw.c2.y, t1, nullptr, MMSA_ACT_RELU, ws.bnws));  // dz2 -> t1
+    RET_IF(bn_bwd(r, bd.c2, bw.c2, t3, nullptr, t1, nullptr, MMSA_ACT_RELU, ws.bnws));  // dz2 -> t1
     RET_IF(conv_wgrad(r, bd.c2, t1, bw.c1.y, r.G(bd.c2.w), acc));
     RET_IF(conv_dgrad(r, bd.c2, t1, t3, nullptr));                                   // dy1 -> t3
-    RET_IF(bn_bwd(r, bd.c1, bw.c1, t3, bw.c1.y, t1, nullptr, MMSA_ACT_RELU, ws.bnws));  // dz1 -> t1
+    RET_IF(bn_bwd(r, bd.c1, bw.c1, t3, nullptr, t1, nullptr, MMSA_ACT_RELU, ws.bnws));  // dz1 -> t1
     if (const char* dbg = getenv("MMSA_RESNET_BWD_STOP_BLOCK")) {  // diagnostic: leave t3 = dy1, t1 = dz1 of block i intact
       if (atoi(dbg) == i) return MMSA_OK;
     }
@@ -373,7 +373,7 @@ int mmsa_resnet_bwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
   // max-pool, stem BN + ReLU, stem conv (weight gradient only: the image needs none)
   const ConvDef& s = L.stem;
   RET_IF(maxpool_bwd(c.dtype, dOut, ws.pool_idx, t1, B, s.Hout, s.Wout, 64, st));
-  RET_IF(bn_bwd(r, s, ws.stem, t1, ws.stem.y, t2, nullptr, MMSA_ACT_RELU, ws.bnws));
+  RET_IF(bn_bwd(r, s, ws.stem, t1, nullptr, t2, nullptr, MMSA_ACT_RELU, ws.bnws));
   const int M0 = B * s.Hout * s.Wout;
   {
     GemmParams p = Eng::blank();

@@ -1,0 +1,140 @@
+"""GPU parity tests of the persistent 3-stage MFMA GEMM (csrc/gemm_mfma2.hip), through the C ABI.
+
+The kernel's hazards are ordering hazards (counted vmcnt waits, one barrier per K step, prefetch across tile
+boundaries), so the cases are chosen to walk every schedule shape: one K step per tile (K = 64), many tiles per
+workgroup (> 256 items), ragged M / N edges, every tile width (MMSA_G2_NJ = 2 / 3 / 4), all four operand layouts,
+split-K slabs, plain and memory-reading epilogues, and the BERT-base shapes at full size. The reference is a
+float32 matmul of the same bf16-rounded operands (torch, on the device); tolerance = bf16 output rounding.
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from multimodal_sentiment_aanalysis_amd import kernels as K
+from multimodal_sentiment_aanalysis_amd._lib import ACT_GELU, GEMM_BF16_MFMA
+
+BF = torch.bfloat16
+
+
+def rnd(shape, dev, seed, scale=1.0, dtype=BF):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def close(got, ref, what, tol=1.2e-2):
+    got = got.float()
+    ref = ref.float()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item() / scale
+    assert err < tol, f"{what}: rel-to-max err {err:.3e} >= {tol}"
+
+
+class force_nj:
+    def __init__(self, nj):
+        self.nj = nj
+
+    def __enter__(self):
+        if self.nj:
+            os.environ["MMSA_G2_NJ"] = str(self.nj)
+
+    def __exit__(self, *a):
+        os.environ.pop("MMSA_G2_NJ", None)
+
+
+SHAPES = [  # M, N, K
+    (256, 128, 64),      # one tile, one step
+    (8192, 64, 64),      # K = 64 stream: one step per tile, 32 tiles
+    (100000, 64, 64),    # > 256 items per launch, ragged last row tile
+    (50000, 256, 128),   # two steps per tile, many tiles, ragged
+    (8192, 768, 768),    # BERT out-proj
+    (8192, 2304, 768),   # BERT QKV
+    (1000, 200, 192),    # ragged M and N (N % 8 == 0), three steps
+    (777, 136, 320),     # ragged, N not a multiple of 16
+]
+
+
+@pytest.mark.parametrize("nj", [0, 2, 3, 4])
+@pytest.mark.parametrize("M,N,Kd", SHAPES)
+def test_g2_nt(dev, M, N, Kd, nj):
+    A = rnd((M, Kd), dev, 1)
+    B = rnd((N, Kd), dev, 2)
+    C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    with force_nj(nj):
+        K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, impl=GEMM_BF16_MFMA)
+    close(C, A.float() @ B.float().T, f"NT nj={nj}")
+
+
+@pytest.mark.parametrize("nj", [0, 2, 3, 4])
+@pytest.mark.parametrize("M,N,Kd", [(8192, 768, 3072), (50000, 64, 256), (1000, 200, 192), (8192, 3072, 768)])
+def test_g2_nn(dev, M, N, Kd, nj):
+    A = rnd((M, Kd), dev, 1)
+    B = rnd((Kd, N), dev, 2)
+    C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    with force_nj(nj):
+        K.gemm(A, B, C, M, N, Kd, Kd, N, N, b_kmajor=1, impl=GEMM_BF16_MFMA)
+    close(C, A.float() @ B.float(), f"NN nj={nj}")
+
+
+@pytest.mark.parametrize("nj", [0, 2, 3, 4])
+@pytest.mark.parametrize("M,N,Kd,split", [(768, 3072, 8192, 8), (64, 576, 200704, 64), (256, 64, 50176, 32),
+                                          (136, 264, 1024, 1), (2304, 768, 8192, 4), (64, 64, 6400, 16)])
+def test_g2_tn_f32(dev, M, N, Kd, split, nj):
+    A = rnd((Kd, M), dev, 1, 0.5)
+    B = rnd((Kd, N), dev, 2, 0.5)
+    C0 = rnd((M, N), dev, 3, dtype=torch.float32)
+    C = C0.clone()
+    with force_nj(nj):
+        K.gemm(A, B, C, M, N, Kd, M, N, N, a_kmajor=1, b_kmajor=1, out_f32=1, accumulate=1, split_k=split,
+               impl=GEMM_BF16_MFMA)
+    ref = C0.double() + A.double().T @ B.double()
+    close(C.double(), ref, f"TN nj={nj}", tol=2e-5)
+    # overwrite mode, bf16-free fp32 store
+    C2 = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+    with force_nj(nj):
+        K.gemm(A, B, C2, M, N, Kd, M, N, N, a_kmajor=1, b_kmajor=1, out_f32=1, split_k=split, impl=GEMM_BF16_MFMA)
+    close(C2.double(), A.double().T @ B.double(), f"TN overwrite nj={nj}", tol=2e-5)
+
+
+@pytest.mark.parametrize("nj", [0, 2, 3, 4])
+def test_g2_tn_kcontig_b(dev, nj):
+    M, N, Kd = 520, 264, 192
+    A = rnd((Kd, M), dev, 1)
+    B = rnd((N, Kd), dev, 2)
+    C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    with force_nj(nj):
+        K.gemm(A, B, C, M, N, Kd, M, Kd, N, a_kmajor=1, b_kmajor=0, impl=GEMM_BF16_MFMA)
+    close(C, A.float().T @ B.float().T, f"TN/kc nj={nj}")
+
+
+@pytest.mark.parametrize("nj", [0, 3])
+@pytest.mark.parametrize("M,N,Kd", [(8192, 3072, 768), (700, 200, 128)])
+def test_g2_epilogues(dev, M, N, Kd, nj):
+    A = rnd((M, Kd), dev, 1, 0.3)
+    B = rnd((N, Kd), dev, 2, 0.3)
+    bias = rnd((N,), dev, 3, dtype=torch.float32)
+    add = rnd((M, N), dev, 4)
+    pre = rnd((M, N), dev, 5)
+    acc = A.float() @ B.float().T + bias
+    C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    C2 = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    with force_nj(nj):
+        K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, bias=bias, C2=C2, ldc2=N, act=ACT_GELU, impl=GEMM_BF16_MFMA)
+        close(C2, acc, "pre-activation")
+        close(C, F.gelu(acc), "gelu")
+        K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, bias=bias, add=add, ldadd=N, impl=GEMM_BF16_MFMA)
+        close(C, acc + add.float(), "bias+residual")
+        x = pre.float()
+        gp = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+        K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, mul=pre, ldmul=N, add=add, ldadd=N, impl=GEMM_BF16_MFMA)
+        close(C, (A.float() @ B.float().T) * gp + add.float(), "gelu-grad")
+        # a plain-store launch right after memory-reading epilogues, then repeated launches must agree bitwise
+        K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, impl=GEMM_BF16_MFMA)
+        first = C.clone()
+        for _ in range(3):
+            K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, impl=GEMM_BF16_MFMA)
+            assert torch.equal(C, first), "repeat launches differ (ordering hazard)"
+    close(first, A.float() @ B.float().T, "plain")
