@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <vector>
 #include "gemm.h"
 #include "gemm_epilogue.h"
 #include "gemm_tile.h"
@@ -279,22 +280,115 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       }
       return p.out_f32 ? 2 : 1;
     }
-    // general epilogue (reads bias / side operands): branches + loads, then a full drain so the counted waits of the
-    // following steps see an empty queue
-    f32x4 bias4[NJ];
+    // general epilogue (reads bias / side operands), then a full drain so the counted waits of the following steps
+    // see an empty queue. All side-operand loads of the tile are issued up front, branch-free through buffer
+    // descriptors (out-of-range lanes read 0), and awaited once: as a per-sub-tile load -> use -> store chain it cost
+    // 16 dependent memory round trips per tile (FFN GEMMs ran at 420-470 TF/s against 750 for the plain store).
+    if (!(p.out_f32 && p.accumulate)) {
+      const long cext = (long)(p.M - 1);
+      f32x4 bias4[NJ];
+      i32x2 side[4][NJ];  // gelu' operand, or the residual when there is no gelu' operand (both: a second batch)
+      const bool has_mul = p.mul != nullptr, has_add = p.add != nullptr;
+      auto load_side = [&](const void* ptr, long ld) __attribute__((always_inline)) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, (int)((cext * ld + p.N) * 2), 0x00020000);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n = nb + j * 16;
-      bias4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = mb + i * 16;
-      if (m >= p.M) continue;
+          for (int j = 0; j < NJ; ++j) {
+            const int m = mb + i * 16, n = nb + j * 16;
+            side[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (m < p.M && n < p.N) ? (int)(((long)m * ld + n) * 2) : OOB, 0, 0);
+          }
+      };
+      {
+        __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.N * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int n = nb + j * 16;
+          bias4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, n < p.N ? n * 4 : OOB, 0, 0));
+        }
+      }
+      if (has_mul) load_side(p.mul, p.ldmul);
+      else if (has_add) load_side(p.add, p.ldadd);
+      __builtin_amdgcn_sched_barrier(0);
+      __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(p.C2, 0, p.C2 ? (int)((cext * p.ldc2 + p.N) * 2) : 0, 0x00020000);
+      const int mrow = mb + ((g4 & 1) << 4), ncol = C.n0 + wn * (NJ * 16) + ((g4 >> 1) << 3);
+      auto unpack = [&](i32x2 v) __attribute__((always_inline)) -> f32x4 {
+        const bf16x4 t = __builtin_bit_cast(bf16x4, v);
+        return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+      };
+      auto store_pair = [&](__amdgpu_buffer_rsrc_t rs, long ld, int m, int n, f32x4 x, f32x4 y) __attribute__((always_inline)) {
+        const bf16x4 xb = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
+        const bf16x4 yb = {(bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
+        const i32x2 xi = __builtin_bit_cast(i32x2, xb), yi = __builtin_bit_cast(i32x2, yb);
+        const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)xi[0], (unsigned)yi[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)xi[1], (unsigned)yi[1], false, false);
+        const i32x4 d = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (m < p.M && n < p.N) ? (int)(((long)m * ld + n) * 2) : OOB, 0, 0);
+      };
+      // pass 1 (in place): + bias, side output, activation, gelu' factor
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) acc[i + h][j] += bias4[j];
+          if (p.C2) store_pair(rc2, p.ldc2, mrow + i * 16, ncol + j * 16, acc[i][j], acc[i + 1][j]);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (p.act != MMSA_ACT_NONE) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[i + h][j][r] = apply_act(acc[i + h][j][r], p.act);
+            }
+            if (has_mul) {
+              const f32x4 x = unpack(side[i + h][j]);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[i + h][j][r] *= gelu_erf_grad(x[r]);
+            }
+          }
+        }
+      }
+      if (has_mul && has_add) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_side(p.add, p.ldadd);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // pass 2: + residual, store
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (has_add) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[i + h][j] += unpack(side[i + h][j]);
+          }
+          if (p.out_f32) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int m = mb + (i + h) * 16, n = nb + j * 16;
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, acc[i + h][j]), rsrcC,
+                                                     (m < p.M && n < p.N) ? (int)(((long)m * p.ldc + n) * 4) : OOB, 0, 0);
+            }
+          } else {
+            store_pair(rsrcC, p.ldc, mrow + i * 16, ncol + j * 16, acc[i][j], acc[i + 1][j]);
+          }
+        }
+      }
+    } else {  // fp32 accumulate into C without a split (rare): per-element read-modify-write
+      f32x4 bias4[NJ];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int n = nb + j * 16;
-        if (n < p.N) gemm_epilogue4b<bf16>(p, m, n, acc[i][j], bias4[j]);
+        bias4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mb + i * 16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int n = nb + j * 16;
+          if (n < p.N) gemm_epilogue4b<bf16>(p, m, n, acc[i][j], bias4[j]);
+        }
       }
     }
     wait_vm<0>();
@@ -500,8 +594,13 @@ bool gemm2_eligible(const GemmParams& p) {
 
 struct G2Plan { int nj, split; };
 
-// tile width and K split that keep the most MFMA slots busy over whole rounds of `cus` workgroups
-static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
+// Tile width and K split. Cost model in microseconds, calibrated on MI355X (profiles/): a K step of the 256-row tile
+// costs about the same for every width (the 32 KiB A tile, the barrier and the LDS traffic dominate; MFMA-only time is
+// 0.19 us per 32 columns): t_step = 1.0 + 0.06 nj; per item 0.3 + 0.2 nj (pipeline bubble + epilogue stores);
+// a split adds the slab round trip at ~4 TB/s and the reducer launch. So: the widest tile that keeps whole rounds of
+// `cus` workgroups busy, and as many K slices as it takes to fill the chip when there are few tiles (weight
+// gradients: 1..72 tiles with K = 8192..802816).
+static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail) {
   const int ntm = cdiv(p.M, G2_BM), nsteps = p.K / G2_BK;
   G2Plan best{4, 1};
   double best_cost = 1e300;
@@ -509,21 +608,45 @@ static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
     const int bn = nj * 32, ntn = cdiv(p.N, bn);
     const long tiles = (long)ntm * ntn;
     int smax = 1;
-    if (ws_bytes_avail > 0 && p.ws) smax = nsteps / 4 < 64 ? (nsteps / 4 > 1 ? nsteps / 4 : 1) : 64;
-    for (int split = 1; split <= smax; ++split) {
-      const int per = cdiv(nsteps, split);
-      if (split > 1 && (per < 4 || (long)(split - 1) * per >= nsteps)) continue;
-      if (split > 1 && (size_t)split * p.M * p.N * sizeof(float) > ws_bytes_avail) continue;
+    if (ws_bytes_avail > 0 && p.ws) {
+      smax = nsteps / 2;
+      if (smax > 256) smax = 256;
+      if (smax < 1) smax = 1;
+      const long cap = (long)(ws_bytes_avail / ((size_t)p.M * p.N * sizeof(float)));
+      if (cap < smax) smax = (int)(cap > 1 ? cap : 1);
+    }
+    int cand[16];
+    int nc = 0;
+    cand[nc++] = 1;
+    for (int r = 1; r <= 6 && smax > 1; ++r) {
+      const long sp = (long)r * cus / tiles;
+      for (long d = sp; d <= sp + 1; ++d)
+        if (d > 1 && d <= smax && nc < 16) cand[nc++] = (int)d;
+    }
+    const double t_step = 1.0 + 0.06 * nj, t_item = 0.3 + 0.2 * nj;
+    const double waste = (double)ntn * bn / p.N;  // padded columns: only as a tie breaker
+    for (int c = 0; c < nc; ++c) {
+      const int per = cdiv(nsteps, cand[c]);
+      const int split = cdiv(nsteps, per);  // no empty slices: e.g. 3136 steps / 256 -> 13 per slice -> 242 slices
       const long items = tiles * split;
       const long rounds = (items + cus - 1) / cus;
-      // cost ~ rounds x (steps per item x MFMA work of a tile + fixed item overhead) + slab traffic
-      // unit = 128 cycles (~53 ns): a K step of a 256 x 32 nj tile is nj units of MFMA work when MFMA-bound
-      double cost = (double)rounds * (per * (double)nj + 3.0);
-      if (split > 1) cost += 8.0 * split * (double)p.M * p.N / 4e12 / 53e-9 + 56.0;  // slab write + read, reduce launch
+      double cost = (double)rounds * (per * t_step + t_item) + 1e-3 * waste;
+      if (split > 1) cost += 3.0 + 2.0 * split * (double)p.M * p.N * 4.0 / 4e6;
       if (cost < best_cost - 1e-9) { best_cost = cost; best = G2Plan{nj, split}; }
     }
   }
   return best;
+}
+
+// plans are pure functions of the shape: memoize (one caller thread per process — include/mmsa.h)
+static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
+  struct Key { int M, N, K; size_t ws; G2Plan plan; };
+  static std::vector<Key> cache;
+  for (const Key& k : cache)
+    if (k.M == p.M && k.N == p.N && k.K == p.K && k.ws == ws_bytes_avail) return k.plan;
+  const G2Plan plan = g2_plan_search(p, cus, ws_bytes_avail);
+  if (cache.size() < 4096) cache.push_back(Key{p.M, p.N, p.K, ws_bytes_avail, plan});
+  return plan;
 }
 
 template <int NJ, bool A_KM, bool B_KM>
