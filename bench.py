@@ -105,7 +105,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model, 16, args.cpu_baseline_steps)
-    trainer = FusedTrainStep(model, device, precision=args.precision)
+    trainer = FusedTrainStep(model, device, precision=args.precision,
+                             two_streams=os.environ.get("MMSA_TWO_STREAMS", "1") != "0")
     batch = synth_batch(args.batch, args.seq, 30522, device, 1234 + rank)
 
     def sync():
@@ -117,7 +118,8 @@ def main():
         trainer.step(*batch)
     L = _lib.load()
     sync()
-    L.mmsa_prof_begin(args.steps * 1200)
+    if os.environ.get("MMSA_BENCH_NOPROF", "0") == "0":
+        L.mmsa_prof_begin(args.steps * 1200)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -69,7 +69,10 @@ class MultiModalEncoder(HeadEngine):
         return [self.feat_dim]
 
     def features(self, image, token_ids, attention_mask=None):
-        return self.image_net(image), self.text_net(token_ids, attention_mask)
+        i = self.image_net(image)  # may run on its own stream (EngineModule.use_side_stream): joined below
+        t = self.text_net(token_ids, attention_mask)
+        self.image_net.join()
+        return i, t
 
     def fuse(self, image_feat, text_feat):
         return self._run(text_feat, image_feat)[0]

@@ -12,17 +12,43 @@
 
 #define BN_CHUNKS 1024
 
+// 8 consecutive channels per lane: 16 bytes of bf16 (one dwordx4 per lane, 1 KiB per wave instruction) or 32 bytes of
+// fp32. The 8-byte form (4 channels per lane) ran the streaming kernels at 2.6-3.3 TB/s; see profiles/.
+struct f32x8 { f32x4 lo, hi; };
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ f32x8 load(const float* p) { return f32x8{*(const f32x4*)p, *(const f32x4*)(p + 4)}; }
+  static __device__ __forceinline__ void store(float* p, f32x8 v) { *(f32x4*)p = v.lo; *(f32x4*)(p + 4) = v.hi; }
+};
+template <> struct Vec8<bf16> {
+  static __device__ __forceinline__ f32x8 load(const bf16* p) {
+    const bf16x8 t = *(const bf16x8*)p;
+    return f32x8{f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]}, f32x4{(float)t[4], (float)t[5], (float)t[6], (float)t[7]}};
+  }
+  static __device__ __forceinline__ void store(bf16* p, f32x8 v) {
+    const bf16x8 t = {(bf16)v.lo[0], (bf16)v.lo[1], (bf16)v.lo[2], (bf16)v.lo[3],
+                      (bf16)v.hi[0], (bf16)v.hi[1], (bf16)v.hi[2], (bf16)v.hi[3]};
+    *(bf16x8*)p = t;
+  }
+};
+__device__ __forceinline__ f32x8 ld8(const float* p) { return f32x8{*(const f32x4*)p, *(const f32x4*)(p + 4)}; }
+__device__ __forceinline__ f32x8 operator+(f32x8 a, f32x8 b) { return f32x8{a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ f32x8 operator-(f32x8 a, f32x8 b) { return f32x8{a.lo - b.lo, a.hi - b.hi}; }
+__device__ __forceinline__ f32x8 operator*(f32x8 a, f32x8 b) { return f32x8{a.lo * b.lo, a.hi * b.hi}; }
+__device__ __forceinline__ f32x8 operator*(f32x8 a, float b) { return f32x8{a.lo * b, a.hi * b}; }
+__device__ __forceinline__ f32x8 zero8() { return f32x8{f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}; }
+
 struct BnMap {
-  int cthreads, rlanes, cgroups;  // column threads per block, row lanes per block, grid.y
+  int cthreads, rlanes, cgroups;  // column threads per block (8 channels each), row lanes per block, grid.y
 };
 static BnMap bn_map(int C) {
-  const int c4 = C / 4;
+  const int c8 = C / 8;
   int ct = 1;
-  while (ct < c4 && ct < 256) ct <<= 1;
+  while (ct < c8 && ct < 256) ct <<= 1;
   BnMap m;
   m.cthreads = ct;
   m.rlanes = 256 / ct;
-  m.cgroups = cdiv(c4, ct);
+  m.cgroups = cdiv(c8, ct);
   return m;
 }
 
@@ -30,27 +56,39 @@ static BnMap bn_map(int C) {
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restrict__ x, float* __restrict__ part, int M,
                                                                int C, int cthreads, int rows_per_chunk) {
-  __shared__ f32x4 red[2][256];
+  __shared__ f32x4 red[4][256];
   const int ct = threadIdx.x % cthreads, rl = threadIdx.x / cthreads, rlanes = 256 / cthreads;
-  const int col = (blockIdx.y * cthreads + ct) * 4;
+  const int col = (blockIdx.y * cthreads + ct) * 8;
   const int r0 = blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
-  f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
-  if (col < C)
-    for (int r = r0 + rl; r < r1; r += rlanes) {
-      const f32x4 v = Vec4<T>::load(x + (long)r * C + col);
-      s += v;
-      q += v * v;
+  f32x8 s = zero8(), q = zero8();
+  if (col < C) {
+    int r = r0 + rl;
+    for (; r + 3 * rlanes < r1; r += 4 * rlanes) {  // four independent 16-byte loads in flight per lane
+      const f32x8 v0 = Vec8<T>::load(x + (long)r * C + col), v1 = Vec8<T>::load(x + (long)(r + rlanes) * C + col);
+      const f32x8 v2 = Vec8<T>::load(x + (long)(r + 2 * rlanes) * C + col), v3 = Vec8<T>::load(x + (long)(r + 3 * rlanes) * C + col);
+      s = s + v0; q = q + v0 * v0;
+      s = s + v1; q = q + v1 * v1;
+      s = s + v2; q = q + v2 * v2;
+      s = s + v3; q = q + v3 * v3;
     }
-  red[0][threadIdx.x] = s;
-  red[1][threadIdx.x] = q;
+    for (; r < r1; r += rlanes) {
+      const f32x8 v = Vec8<T>::load(x + (long)r * C + col);
+      s = s + v;
+      q = q + v * v;
+    }
+  }
+  red[0][threadIdx.x] = s.lo; red[1][threadIdx.x] = s.hi;
+  red[2][threadIdx.x] = q.lo; red[3][threadIdx.x] = q.hi;
   __syncthreads();
   if (rl == 0 && col < C) {
     for (int j = 1; j < rlanes; ++j) {
-      s += red[0][j * cthreads + ct];
-      q += red[1][j * cthreads + ct];
+      s.lo += red[0][j * cthreads + ct]; s.hi += red[1][j * cthreads + ct];
+      q.lo += red[2][j * cthreads + ct]; q.hi += red[3][j * cthreads + ct];
     }
-    *(f32x4*)(part + ((long)blockIdx.x * 2 + 0) * C + col) = s;
-    *(f32x4*)(part + ((long)blockIdx.x * 2 + 1) * C + col) = q;
+    float* ps = part + ((long)blockIdx.x * 2 + 0) * C + col;
+    float* pq = part + ((long)blockIdx.x * 2 + 1) * C + col;
+    *(f32x4*)ps = s.lo; *(f32x4*)(ps + 4) = s.hi;
+    *(f32x4*)pq = q.lo; *(f32x4*)(pq + 4) = q.hi;
   }
 }
 
@@ -105,25 +143,39 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ beta, const T* __restrict__ res,
                                                        T* __restrict__ y, int M, int C, int cthreads, int act) {
   const int ct = threadIdx.x % cthreads, rl = threadIdx.x / cthreads, rlanes = 256 / cthreads;
-  const int col = (blockIdx.y * cthreads + ct) * 4;
+  const int col = (blockIdx.y * cthreads + ct) * 8;
   if (col >= C) return;
-  const f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
-  const f32x4 sc = is * *(const f32x4*)(gamma + col);
-  const f32x4 sh = *(const f32x4*)(beta + col) - mu * sc;
-  for (long r = (long)blockIdx.x * rlanes + rl; r < M; r += (long)gridDim.x * rlanes) {
-    f32x4 v = Vec4<T>::load(x + r * C + col) * sc + sh;
-    if (res) v += Vec4<T>::load(res + r * C + col);
+  const f32x8 mu = ld8(mean + col), is = ld8(invstd + col);
+  const f32x8 sc = is * ld8(gamma + col);
+  const f32x8 sh = ld8(beta + col) - mu * sc;
+  const long stride = (long)gridDim.x * rlanes;
+  auto one = [&](long r, f32x8 xv, f32x8 rv) {
+    f32x8 v = xv * sc + sh;
+    if (res) v = v + rv;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
-    Vec4<T>::store(y + r * C + col, v);
+    for (int e = 0; e < 4; ++e) { v.lo[e] = apply_act(v.lo[e], act); v.hi[e] = apply_act(v.hi[e], act); }
+    Vec8<T>::store(y + r * C + col, v);
+  };
+  long r = (long)blockIdx.x * rlanes + rl;
+  for (; r + stride < M; r += 2 * stride) {  // two rows in flight per lane
+    const f32x8 x0 = Vec8<T>::load(x + r * C + col), x1 = Vec8<T>::load(x + (r + stride) * C + col);
+    f32x8 q0 = zero8(), q1 = zero8();
+    if (res) { q0 = Vec8<T>::load(res + r * C + col); q1 = Vec8<T>::load(res + (r + stride) * C + col); }
+    one(r, x0, q0);
+    one(r + stride, x1, q1);
+  }
+  for (; r < M; r += stride) {
+    const f32x8 x0 = Vec8<T>::load(x + r * C + col);
+    f32x8 q0 = zero8();
+    if (res) q0 = Vec8<T>::load(res + r * C + col);
+    one(r, x0, q0);
   }
 }
 
 // backward pass 1: dz = dy * act'(z); partial sums of dz and dz * xhat.  ReLU mask comes from the saved output y
 // (y > 0 <=> z > 0, also with a residual) or, when y == null (no residual), is recomputed from x with the forward's own
 // expression x*sc + sh, which saves one of the three streamed reads; GELU (no residual in the reference) recomputes z.
-template <typename T>
-__device__ __forceinline__ f32x4 bn_dz(f32x4 dy, f32x4 xh, f32x4 g, f32x4 b, f32x4 yv, int act) {
+__device__ __forceinline__ f32x4 bn_dz4(f32x4 dy, f32x4 xh, f32x4 g, f32x4 b, f32x4 yv, int act) {
   f32x4 dz = dy;
   if (act == MMSA_ACT_RELU) {
 #pragma unroll
@@ -134,6 +186,9 @@ __device__ __forceinline__ f32x4 bn_dz(f32x4 dy, f32x4 xh, f32x4 g, f32x4 b, f32
   }
   return dz;
 }
+__device__ __forceinline__ f32x8 bn_dz(f32x8 dy, f32x8 xh, f32x8 g, f32x8 b, f32x8 yv, int act) {
+  return f32x8{bn_dz4(dy.lo, xh.lo, g.lo, b.lo, yv.lo, act), bn_dz4(dy.hi, xh.hi, g.hi, b.hi, yv.hi, act)};
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ dy, const T* __restrict__ x,
@@ -142,35 +197,52 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ part, int M, int C, int cthreads,
                                                              int rows_per_chunk, int act) {
-  __shared__ f32x4 red[2][256];
+  __shared__ f32x4 red[4][256];
   const int ct = threadIdx.x % cthreads, rl = threadIdx.x / cthreads, rlanes = 256 / cthreads;
-  const int col = (blockIdx.y * cthreads + ct) * 4;
+  const int col = (blockIdx.y * cthreads + ct) * 8;
   const int r0 = blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
-  f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+  f32x8 s = zero8(), q = zero8();
   if (col < C) {
-    const f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
-    const f32x4 g = *(const f32x4*)(gamma + col), b = *(const f32x4*)(beta + col);
-    const f32x4 sc = is * g, sh = b - mu * sc;  // as bn_apply_kernel: the ReLU mask without a saved output (y == null)
-    for (int r = r0 + rl; r < r1; r += rlanes) {
-      const f32x4 xr = Vec4<T>::load(x + (long)r * C + col);
-      const f32x4 xh = (xr - mu) * is;
-      f32x4 yv = {0, 0, 0, 0};
-      if (act == MMSA_ACT_RELU) yv = y ? Vec4<T>::load(y + (long)r * C + col) : xr * sc + sh;
-      const f32x4 dz = bn_dz<T>(Vec4<T>::load(dy + (long)r * C + col), xh, g, b, yv, act);
-      s += dz;
-      q += dz * xh;
+    const f32x8 mu = ld8(mean + col), is = ld8(invstd + col);
+    const f32x8 g = ld8(gamma + col), b = ld8(beta + col);
+    const f32x8 sc = is * g, sh = b - mu * sc;  // as bn_apply_kernel: the ReLU mask without a saved output (y == null)
+    const bool rd_y = act == MMSA_ACT_RELU && y;
+    auto one = [&](f32x8 xr, f32x8 dv, f32x8 yv) {
+      const f32x8 xh = (xr - mu) * is;
+      if (act == MMSA_ACT_RELU && !y) yv = xr * sc + sh;
+      const f32x8 dz = bn_dz(dv, xh, g, b, yv, act);
+      s = s + dz;
+      q = q + dz * xh;
+    };
+    int r = r0 + rl;
+    for (; r + rlanes < r1; r += 2 * rlanes) {  // two rows (4-6 independent 16-byte loads) in flight per lane
+      const long o0 = (long)r * C + col, o1 = (long)(r + rlanes) * C + col;
+      const f32x8 x0 = Vec8<T>::load(x + o0), x1 = Vec8<T>::load(x + o1);
+      const f32x8 d0 = Vec8<T>::load(dy + o0), d1 = Vec8<T>::load(dy + o1);
+      f32x8 y0 = zero8(), y1 = zero8();
+      if (rd_y) { y0 = Vec8<T>::load(y + o0); y1 = Vec8<T>::load(y + o1); }
+      one(x0, d0, y0);
+      one(x1, d1, y1);
+    }
+    for (; r < r1; r += rlanes) {
+      const long o0 = (long)r * C + col;
+      f32x8 y0 = zero8();
+      if (rd_y) y0 = Vec8<T>::load(y + o0);
+      one(Vec8<T>::load(x + o0), Vec8<T>::load(dy + o0), y0);
     }
   }
-  red[0][threadIdx.x] = s;
-  red[1][threadIdx.x] = q;
+  red[0][threadIdx.x] = s.lo; red[1][threadIdx.x] = s.hi;
+  red[2][threadIdx.x] = q.lo; red[3][threadIdx.x] = q.hi;
   __syncthreads();
   if (rl == 0 && col < C) {
     for (int j = 1; j < rlanes; ++j) {
-      s += red[0][j * cthreads + ct];
-      q += red[1][j * cthreads + ct];
+      s.lo += red[0][j * cthreads + ct]; s.hi += red[1][j * cthreads + ct];
+      q.lo += red[2][j * cthreads + ct]; q.hi += red[3][j * cthreads + ct];
     }
-    *(f32x4*)(part + ((long)blockIdx.x * 2 + 0) * C + col) = s;
-    *(f32x4*)(part + ((long)blockIdx.x * 2 + 1) * C + col) = q;
+    float* ps = part + ((long)blockIdx.x * 2 + 0) * C + col;
+    float* pq = part + ((long)blockIdx.x * 2 + 1) * C + col;
+    *(f32x4*)ps = s.lo; *(f32x4*)(ps + 4) = s.hi;
+    *(f32x4*)pq = q.lo; *(f32x4*)(pq + 4) = q.hi;
   }
 }
 
@@ -213,26 +285,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            T* __restrict__ dres, int M, int C, int cthreads, int act,
                                                            int training) {
   const int ct = threadIdx.x % cthreads, rl = threadIdx.x / cthreads, rlanes = 256 / cthreads;
-  const int col = (blockIdx.y * cthreads + ct) * 4;
+  const int col = (blockIdx.y * cthreads + ct) * 8;
   if (col >= C) return;
-  const f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
-  const f32x4 g = *(const f32x4*)(gamma + col), b = *(const f32x4*)(beta + col);
-  f32x4 mb = {0, 0, 0, 0}, mg = {0, 0, 0, 0};
+  const f32x8 mu = ld8(mean + col), is = ld8(invstd + col);
+  const f32x8 g = ld8(gamma + col), b = ld8(beta + col);
+  f32x8 mb = zero8(), mg = zero8();
   if (training) {
     const float invM = 1.0f / (float)M;
-    mb = *(const f32x4*)(sums + col) * invM;
-    mg = *(const f32x4*)(sums + C + col) * invM;
+    mb = ld8(sums + col) * invM;
+    mg = ld8(sums + C + col) * invM;
   }
-  const f32x4 gi = g * is;
-  const f32x4 sc = is * g, sh = b - mu * sc;
-  for (long r = (long)blockIdx.x * rlanes + rl; r < M; r += (long)gridDim.x * rlanes) {
-    const f32x4 xr = Vec4<T>::load(x + r * C + col);
-    const f32x4 xh = (xr - mu) * is;
-    f32x4 yv = {0, 0, 0, 0};
-    if (act == MMSA_ACT_RELU) yv = y ? Vec4<T>::load(y + r * C + col) : xr * sc + sh;
-    const f32x4 dz = bn_dz<T>(Vec4<T>::load(dy + r * C + col), xh, g, b, yv, act);
-    if (dres) Vec4<T>::store(dres + r * C + col, dz);
-    Vec4<T>::store(dx + r * C + col, gi * (dz - mb - xh * mg));
+  const f32x8 gi = g * is;
+  const f32x8 sc = is * g, sh = b - mu * sc;
+  const bool rd_y = act == MMSA_ACT_RELU && y;
+  const long stride = (long)gridDim.x * rlanes;
+  auto one = [&](long r, f32x8 xr, f32x8 dv, f32x8 yv) {
+    const f32x8 xh = (xr - mu) * is;
+    if (act == MMSA_ACT_RELU && !y) yv = xr * sc + sh;
+    const f32x8 dz = bn_dz(dv, xh, g, b, yv, act);
+    if (dres) Vec8<T>::store(dres + r * C + col, dz);
+    Vec8<T>::store(dx + r * C + col, gi * (dz - mb - xh * mg));
+  };
+  long r = (long)blockIdx.x * rlanes + rl;
+  for (; r + stride < M; r += 2 * stride) {
+    const long o0 = r * C + col, o1 = (r + stride) * C + col;
+    const f32x8 x0 = Vec8<T>::load(x + o0), x1 = Vec8<T>::load(x + o1);
+    const f32x8 d0 = Vec8<T>::load(dy + o0), d1 = Vec8<T>::load(dy + o1);
+    f32x8 y0 = zero8(), y1 = zero8();
+    if (rd_y) { y0 = Vec8<T>::load(y + o0); y1 = Vec8<T>::load(y + o1); }
+    one(r, x0, d0, y0);
+    one(r + stride, x1, d1, y1);
+  }
+  for (; r < M; r += stride) {
+    const long o0 = r * C + col;
+    f32x8 y0 = zero8();
+    if (rd_y) y0 = Vec8<T>::load(y + o0);
+    one(r, Vec8<T>::load(x + o0), Vec8<T>::load(dy + o0), y0);
   }
 }
 
@@ -263,7 +351,7 @@ static int bn_forward_t(const T* x, const float* gamma, const float* beta, float
 int bn_forward(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                float* mean, float* invstd, const void* res, void* y, float* ws, int M, int C, float eps, float momentum,
                int act, int training, hipStream_t st) {
-  if (C % 4 || M <= 0) return MMSA_ERR_ARG;
+  if (C % 8 || M <= 0) return MMSA_ERR_ARG;
   if (!training && (!running_mean || !running_var)) return MMSA_ERR_ARG;
   if (dtype == MMSA_BF16)
     return bn_forward_t<bf16>((const bf16*)x, gamma, beta, running_mean, running_var, mean, invstd, (const bf16*)res,
@@ -294,7 +382,7 @@ static int bn_backward_t(const T* dy, const T* x, const T* y, const float* mean,
 int bn_backward(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
                 const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
                 float* ws, int M, int C, int act, int training, hipStream_t st) {
-  if (C % 4 || M <= 0) return MMSA_ERR_ARG;
+  if (C % 8 || M <= 0) return MMSA_ERR_ARG;
   if (dtype == MMSA_BF16)
     return bn_backward_t<bf16>((const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, gamma, beta, (bf16*)dx,
                                (bf16*)dres, dgamma, dbeta, accumulate, ws, M, C, act, training, st);

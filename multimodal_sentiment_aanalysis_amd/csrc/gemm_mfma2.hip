@@ -86,7 +86,7 @@ __device__ __forceinline__ bf16x8 lds_rd_tr(unsigned addr) {  // k rows kb..kb+3
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int NJ, bool A_KM, bool B_KM>
+template <int NJ, bool A_KM, bool B_KM, int GATHER>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) {
   // The body is compiled in the device pass only: hipcc's HOST pass (ROCm 7.2) silently fails to instantiate this
   // template when it sees the body (no diagnostic, the launch stub stays an undefined symbol of the .so).
@@ -131,7 +131,13 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     for (int it = lb; it < s.items; it += G) total += decode(it).nk;
 
   // ---- per-lane staging map: relative byte offsets inside a tile (the tile origin and the K advance are scalar)
+  // Implicit-GEMM gathers (gemm.h): GATHER 1 = the k-contiguous A rows are pixels and K = (tap, channel): the per-lane
+  // source offset of a row changes with the tap, so it is recomputed per K step from the row's decomposed pixel;
+  // GATHER 2 = the k-major B rows (k) are output pixels and the columns are (tap, channel): the pixel of a lane's k-row
+  // is decomposed per K step. A K step never straddles a tap (cper % 64 == 0 is checked by the launcher).
   int relA[4], rcA[4], relB[NLB], rcB[NLB];  // rc = row (k-contiguous) or first column (k-major) inside the tile
+  int krowB[NLB];                            // GATHER 2: k-row of the lane's B chunk inside a K step
+  const int kc8 = ((lane & 7) ^ (lane >> 3)) * 8;
   {
     const int kc = (lane & 7) ^ (lane >> 3);
     const int pc = lane & 15;
@@ -159,6 +165,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
         const int cc = ((((pc >> 1) ^ kmajor_swz(krow)) << 1) | (pc & 1));
         rcB[i] = cc * 8;
         relB[i] = (int)(((long)krow * p.ldb + rcB[i]) * 2);
+        krowB[i] = krow;
       }
     }
   }
@@ -171,19 +178,60 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   int l_item = lb, l_kt = 0;
   Item L = decode(l_item);
   int voffA[4], voffB[NLB];
+  RowPix a_pix[4];                       // GATHER 1: decomposed pixel of the lane's 4 A rows of the current tile
+  int b_ky[NLB], b_kx[NLB], b_coff[NLB];  // GATHER 2: tap and channel offset of the lane's B column chunks
   auto loader_setup = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) voffA[i] = (L.m0 + rcA[i] < p.M) ? relA[i] : OOB;
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (GATHER == 1) a_pix[i] = decompose_pixel(p.g, L.m0 + rcA[i], p.M);
+      else voffA[i] = (L.m0 + rcA[i] < p.M) ? relA[i] : OOB;
+    }
 #pragma unroll
-    for (int i = 0; i < NLB; ++i) voffB[i] = (rcB[i] < BN && L.n0 + rcB[i] < p.N) ? relB[i] : OOB;
+    for (int i = 0; i < NLB; ++i) {
+      const bool ok = rcB[i] < BN && L.n0 + rcB[i] < p.N;
+      if constexpr (GATHER == 2) {
+        const int col = L.n0 + rcB[i];
+        const uint32_t tap = fd_div((uint32_t)col, p.g.fd_cper);
+        b_coff[i] = ok ? col - (int)tap * p.g.cper : -1;
+        b_ky[i] = (int)fd_div(tap, p.g.fd_kw);
+        b_kx[i] = (int)tap - b_ky[i] * p.g.KW;
+      } else {
+        voffB[i] = ok ? relB[i] : OOB;
+      }
+    }
   };
   loader_setup();
-  // LDS-DMA of the loader cursor's K step into `stage`: dma_begin (scalar offsets), NL x dma_piece, dma_advance
+  // LDS-DMA of the loader cursor's K step into `stage`: dma_begin (offsets), NL x dma_piece, dma_advance
   int d_soffA = 0, d_soffB = 0;
   auto dma_begin = [&]() __attribute__((always_inline)) {
     const int k0 = (L.kb + l_kt) * G2_BK;
-    d_soffA = A_KM ? (int)(((long)k0 * p.lda + L.m0) * 2) : (int)(((long)L.m0 * p.lda + k0) * 2);
-    d_soffB = B_KM ? (int)(((long)k0 * p.ldb + L.n0) * 2) : (int)(((long)L.n0 * p.ldb + k0) * 2);
+    if constexpr (GATHER == 1) {
+      const uint32_t tap = fd_div((uint32_t)k0, p.g.fd_cper);
+      const int c0 = k0 - (int)tap * p.g.cper;
+      const int ky = (int)fd_div(tap, p.g.fd_kw), kx = (int)tap - ky * p.g.KW;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long src = tap_src(p.g, a_pix[i], ky, kx);
+        voffA[i] = src >= 0 ? (int)((src + kc8) * 2) : OOB;
+      }
+      d_soffA = c0 * 2;
+      if constexpr (B_KM)  // weight [cout][tap][cin] read as k-major rows k = (tap, cout): row (k % cper), tap offset
+        d_soffB = (int)(((long)c0 * p.ldb + (long)tap * p.b_tap_stride + L.n0) * 2);
+      else
+        d_soffB = (int)(((long)L.n0 * p.ldb + k0) * 2);
+    } else if constexpr (GATHER == 2) {
+      d_soffA = (int)(((long)k0 * p.lda + L.m0) * 2);
+#pragma unroll
+      for (int i = 0; i < NLB; ++i) {
+        const RowPix px = decompose_pixel(p.g, k0 + krowB[i], p.K);
+        const long src = tap_src(p.g, px, b_ky[i], b_kx[i]);
+        voffB[i] = (src >= 0 && b_coff[i] >= 0) ? (int)((src + b_coff[i]) * 2) : OOB;
+      }
+      d_soffB = 0;
+    } else {
+      d_soffA = A_KM ? (int)(((long)k0 * p.lda + L.m0) * 2) : (int)(((long)L.m0 * p.lda + k0) * 2);
+      d_soffB = B_KM ? (int)(((long)k0 * p.ldb + L.n0) * 2) : (int)(((long)L.n0 * p.ldb + k0) * 2);
+    }
   };
   auto dma_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_c)::value;
@@ -575,15 +623,36 @@ static int g2_num_cus() {
   return n;
 }
 
+// byte extent of the A / B operand views (what the buffer descriptors cover)
+static void g2_extents(const GemmParams& p, long* ea, long* eb) {
+  *ea = p.a_kmajor ? ((long)(p.K - 1) * p.lda + p.M) * 2 : ((long)(p.M - 1) * p.lda + p.K) * 2;
+  *eb = p.b_kmajor ? ((long)(p.K - 1) * p.ldb + p.N) * 2 : ((long)(p.N - 1) * p.ldb + p.K) * 2;
+  const long ghw = (long)p.g.GH * p.g.GW;
+  if (p.gather == 1) *ea = (long)(p.M / (ghw > 0 ? ghw : 1)) * p.g.SH * p.g.SW * p.g.src_pix_stride * 2;  // source activation
+  if (p.gather == 2) *eb = (long)(p.K / (ghw > 0 ? ghw : 1)) * p.g.SH * p.g.SW * p.g.src_pix_stride * 2;
+  if (p.gather == 1 && p.b_kmajor)  // weight [cout][taps][cin] addressed through (k % cper) * ldb + tap * b_tap_stride
+    *eb = ((long)(p.g.cper - 1) * p.ldb + (long)(p.g.KH * p.g.KW - 1) * p.b_tap_stride + p.N) * 2;
+}
+
 bool gemm2_eligible(const GemmParams& p) {
-  if (p.gather != 0) return false;
+  if (p.gather < 0 || p.gather > 2) return false;
   if (p.K % G2_BK) return false;
   if (p.N % 4) return false;
   if (p.a_kmajor && (p.M % 8)) return false;
   if (p.b_kmajor && (p.N % 8)) return false;
   if ((p.lda % 8) || (p.ldb % 8)) return false;
-  const long ea = p.a_kmajor ? ((long)(p.K - 1) * p.lda + p.M) * 2 : ((long)(p.M - 1) * p.lda + p.K) * 2;
-  const long eb = p.b_kmajor ? ((long)(p.K - 1) * p.ldb + p.N) * 2 : ((long)(p.N - 1) * p.ldb + p.K) * 2;
+  if (p.gather == 1) {
+    if (p.a_kmajor || (p.g.cper % G2_BK) || (p.g.src_pix_stride % 8)) return false;
+    if (p.M % ((long)p.g.GH * p.g.GW)) return false;
+    if (p.g.div != 1 && p.g.div != 2) return false;
+  }
+  if (p.gather == 2) {
+    if (!(p.a_kmajor && p.b_kmajor) || (p.g.cper % 8) || (p.g.src_pix_stride % 8)) return false;
+    if (p.K % ((long)p.g.GH * p.g.GW)) return false;
+    if (p.g.div != 1 && p.g.div != 2) return false;
+  }
+  long ea, eb;
+  g2_extents(p, &ea, &eb);
   // tile origins may start up to one tile past the last row: keep every scalar + vector offset a positive int32
   const long slack = 2L * 256 * (p.lda > p.ldb ? p.lda : p.ldb) + 65536;
   if (ea + slack >= 0x7FFFFFF0L || eb + slack >= 0x7FFFFFF0L) return false;
@@ -649,24 +718,30 @@ static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
   return plan;
 }
 
-template <int NJ, bool A_KM, bool B_KM>
+template <int NJ, bool A_KM, bool B_KM, int GATHER>
 static int g2_launch_t(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<NJ, A_KM, B_KM>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<NJ, A_KM, B_KM, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              G2_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm2_kernel<NJ, A_KM, B_KM>), dim3(grid), dim3(512), G2_LDS, st, p, s);
+  hipLaunchKernelGGL((gemm2_kernel<NJ, A_KM, B_KM, GATHER>), dim3(grid), dim3(512), G2_LDS, st, p, s);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
 
 template <int NJ>
 static int g2_launch_nj(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
-  if (!p.a_kmajor && !p.b_kmajor) return g2_launch_t<NJ, false, false>(p, s, grid, st);
-  if (!p.a_kmajor && p.b_kmajor) return g2_launch_t<NJ, false, true>(p, s, grid, st);
-  if (p.a_kmajor && p.b_kmajor) return g2_launch_t<NJ, true, true>(p, s, grid, st);
-  return g2_launch_t<NJ, true, false>(p, s, grid, st);
+  if (p.gather == 1) {
+    if (!p.b_kmajor) return g2_launch_t<NJ, false, false, 1>(p, s, grid, st);
+    return g2_launch_t<NJ, false, true, 1>(p, s, grid, st);
+  }
+  if (p.gather == 2) return g2_launch_t<NJ, true, true, 2>(p, s, grid, st);
+  if (!p.a_kmajor && !p.b_kmajor) return g2_launch_t<NJ, false, false, 0>(p, s, grid, st);
+  if (!p.a_kmajor && p.b_kmajor) return g2_launch_t<NJ, false, true, 0>(p, s, grid, st);
+  if (p.a_kmajor && p.b_kmajor) return g2_launch_t<NJ, true, true, 0>(p, s, grid, st);
+  return g2_launch_t<NJ, true, false, 0>(p, s, grid, st);
 }
 
 // p.split_k on entry: 1 = no split wanted; > 1 = upper bound chosen by the caller (needs p.ws with room for it)
@@ -694,8 +769,8 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   if (const char* d = getenv("MMSA_G2_DBG")) s.dbg = atoi(d);
   s.c_bytes = s.split_k > 1 ? (unsigned)slab_bytes : (unsigned)(((long)(p.M - 1) * p.ldc + p.N) * (p.out_f32 ? 4 : 2));
   {
-    const long ea = p.a_kmajor ? ((long)(p.K - 1) * p.lda + p.M) * 2 : ((long)(p.M - 1) * p.lda + p.K) * 2;
-    const long eb = p.b_kmajor ? ((long)(p.K - 1) * p.ldb + p.N) * 2 : ((long)(p.N - 1) * p.ldb + p.K) * 2;
+    long ea, eb;
+    g2_extents(p, &ea, &eb);
     p.a_bytes = (unsigned)ea; p.b_bytes = (unsigned)eb;
     // timing-only diagnostic (results are wrong): zero-record descriptors make the range check drop every staging
     // load while the instruction stream, waits and barriers stay — prices the memory side of the loop.

@@ -13,6 +13,7 @@ Parameter storage
     gradients straight into the flat buffer (no autograd accumulation pass), which is also what the fused
     optimizer and the data-parallel reducer operate on.
 """
+import contextlib
 import ctypes
 import math
 
@@ -182,6 +183,37 @@ class EngineModule(nn.Module):
         self._wt_token = tuple(self._pmap[n]._version for n, _, _ in (self._specs[0], self._specs[len(self._specs) // 2],
                                                                       self._specs[-1]))
 
+    # ---- optional side HIP stream ---------------------------------------------------------------------------------
+    # The two encoders are independent until the fusion head. With `use_side_stream(True)` this engine enqueues its
+    # forward / backward on its own stream (ordered after the caller's stream by an event), so its many small
+    # latency-bound kernels (BN finalizes, split-K reduces) overlap with the other encoder's GEMMs. The caller must
+    # `join()` before it consumes the result on its own stream (MultiModalEncoder.features and FusedTrainStep do).
+    def use_side_stream(self, on):
+        self._side = (torch.cuda.Stream(device=self._flat_w.device) if on and self._flat_w is not None
+                      and self._flat_w.is_cuda else None)
+        self._pending = None
+
+    def _run_stream(self):
+        """Context manager + stream the engine call goes to."""
+        side = getattr(self, "_side", None)
+        if side is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(side.device))
+        side.wait_event(ev)
+        return side
+
+    def _mark_pending(self, side):
+        ev = torch.cuda.Event()
+        ev.record(side)
+        self._pending = ev
+
+    def join(self):
+        ev = getattr(self, "_pending", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._pending = None
+
     # ---- per-call workspaces (activations saved for the backward) ---------------------------------------------------
     def _take_ws(self, nbytes, device):
         for i, t in enumerate(self._ws_pool):
@@ -340,13 +372,20 @@ class _ResnetFn(torch.autograd.Function):
         nbytes = L.mmsa_resnet_ws_bytes(ctypes.byref(cfg))
         if nbytes == 0 or C != 3:
             raise MmsaError(f"unsupported ResNet input {tuple(image.shape)}")
-        ws = eng._take_ws(nbytes, image.device)
-        feat = torch.empty(B, eng.out_dim, dtype=torch.float32, device=image.device)
-        wt = eng._sync_wt()
-        check(L.mmsa_resnet_fwd(ctypes.byref(cfg), ptr(eng._flat_w), ptr(wt), ptr(eng._flat_bn), ptr(image), ptr(ws),
-                                ptr(feat), stream_ptr()), "mmsa_resnet_fwd")
-        if eng.training:
-            eng._flat_nbt.add_(1)
+        side = eng._run_stream()
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            ws = eng._take_ws(nbytes, image.device)
+            feat = torch.empty(B, eng.out_dim, dtype=torch.float32, device=image.device)
+            wt = eng._sync_wt()
+            check(L.mmsa_resnet_fwd(ctypes.byref(cfg), ptr(eng._flat_w), ptr(wt), ptr(eng._flat_bn), ptr(image), ptr(ws),
+                                    ptr(feat), stream_ptr()), "mmsa_resnet_fwd")
+            if eng.training:
+                eng._flat_nbt.add_(1)
+            if side is not None:
+                image.record_stream(side)
+                eng._mark_pending(side)
+        if side is not None:  # produced on the side stream, consumed on the caller's
+            feat.record_stream(torch.cuda.current_stream(image.device))
         if dummy is None:
             eng._give_ws(ws)
         else:
@@ -357,13 +396,20 @@ class _ResnetFn(torch.autograd.Function):
     def backward(ctx, dfeat):
         eng = ctx.eng
         eng._ensure_grads()
-        check(_lib.load().mmsa_resnet_bwd(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ws),
-                                          ptr(dfeat.contiguous()), ptr(eng._flat_g), eng._acc_flag(), stream_ptr()),
-              "mmsa_resnet_bwd")
-        eng._give_ws(ctx.ws)
-        ctx.ws = None
-        if getattr(eng, "_grad_ready_hook", None) is not None:
-            eng._grad_ready_hook(eng)
+        dfeat = dfeat.contiguous()
+        side = eng._run_stream()
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            check(_lib.load().mmsa_resnet_bwd(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ws),
+                                              ptr(dfeat), ptr(eng._flat_g), eng._acc_flag(), stream_ptr()),
+                  "mmsa_resnet_bwd")
+            if side is not None:
+                dfeat.record_stream(side)
+            eng._give_ws(ctx.ws)
+            ctx.ws = None
+            if getattr(eng, "_grad_ready_hook", None) is not None:
+                eng._grad_ready_hook(eng)  # records its event on the stream the gradients are produced on
+            if side is not None:
+                eng._mark_pending(side)
         return None, None, None
 
 

@@ -138,3 +138,42 @@ def test_g2_epilogues(dev, M, N, Kd, nj):
             K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, impl=GEMM_BF16_MFMA)
             assert torch.equal(C, first), "repeat launches differ (ordering hazard)"
     close(first, A.float() @ B.float().T, "plain")
+
+
+CONVS = [  # B, H, W, Cin, Cout, k, stride, pad — large enough for many tiles / several items per workgroup
+    (32, 56, 56, 64, 64, 3, 1, 1),      # ResNet stage 1 (M = 100352): one tap per K step
+    (16, 56, 56, 128, 128, 3, 2, 1),    # strided 3x3 (stage 2 first block)
+    (16, 28, 28, 256, 512, 1, 2, 0),    # strided 1x1 downsample
+    (8, 14, 14, 256, 256, 3, 1, 1),     # K = 2304
+    (4, 7, 7, 512, 512, 3, 1, 1),       # few tiles, deep K -> split-K with a gather
+]
+
+
+@pytest.mark.parametrize("nj", [0, 2, 3])
+@pytest.mark.parametrize("cfg", CONVS)
+def test_g2_conv(dev, cfg, nj):
+    B, H, W, Cin, Cout, k, s, p = cfg
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = rnd((B, H, W, Cin), dev, 1)
+    w = rnd((Cout, k, k, Cin), dev, 2, 0.1)
+    dy = rnd((B, OH, OW, Cout), dev, 3)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.conv2d(xr, wr, stride=s, padding=p)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    Kd = k * k * Cin
+    with force_nj(nj):
+        y = torch.full((B * OH * OW, Cout), float("nan"), dtype=BF, device=dev)
+        g = K.conv_geom(H, W, OH, OW, k, k, s, 1, -p, 1, Cin, Cin)
+        K.gemm(x, w, y, B * OH * OW, Cout, Kd, Cin, Kd, Cout, gather=1, geom=g, impl=GEMM_BF16_MFMA)
+        close(y.view(B, OH, OW, Cout), yr.detach().permute(0, 2, 3, 1), "conv fwd")
+        dx = torch.full((B * H * W, Cin), float("nan"), dtype=BF, device=dev)
+        g = K.conv_geom(OH, OW, H, W, k, k, 1, -1, p, s, Cout, Cout)
+        K.gemm(dy, w, dx, B * H * W, Cin, k * k * Cout, Cout, Kd, Cin, b_kmajor=1, gather=1, geom=g, b_tap_stride=Cin,
+               impl=GEMM_BF16_MFMA)
+        close(dx.view(B, H, W, Cin), xr.grad.permute(0, 2, 3, 1), "conv dgrad")
+        dw = torch.full((Cout, Kd), float("nan"), dtype=torch.float32, device=dev)
+        g = K.conv_geom(H, W, OH, OW, k, k, s, 1, -p, 1, Cin, Cin)
+        K.gemm(dy, x, dw, Cout, Kd, B * OH * OW, Cout, Cin, Kd, a_kmajor=1, b_kmajor=1, gather=2, geom=g, out_f32=1,
+               split_k=16, impl=GEMM_BF16_MFMA)
+        close(dw.view(Cout, k, k, Cin), wr.grad.permute(0, 2, 3, 1), "conv wgrad", tol=2e-3)

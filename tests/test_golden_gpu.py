@@ -80,7 +80,10 @@ def test_a2_mm_fusion(dev):
         m.to(dev).train(mode == "train")
         feats = [d[f"f{i}"].to(dev).requires_grad_(True) for i in range(3)]
         out = m._run(*feats)[0]
-        close(out, d[f"{mode}.out"], 1e-5, f"A2 {mode} out")
+        # 3e-5: train mode ends in BatchNorm over 16 rows; the fp32 summation order of the batch statistics differs
+        # from torch's (8-channel lanes, fixed tree), worth 1-2e-5 relative on the normalised output. The north-star
+        # bound is 1e-3 on logits.
+        close(out, d[f"{mode}.out"], 3e-5, f"A2 {mode} out")
         (out * d["wgt"].to(dev)).sum().backward()
         for i in range(3):
             close(feats[i].grad, d[f"{mode}.df{i}"], 2e-4, f"A2 {mode} df{i}")
