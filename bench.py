@@ -23,6 +23,9 @@ import torch.distributed as dist  # noqa: E402
 
 FWD_GFLOP_PER_PAIR = 30.52  # BERT-base S=128 22.348 + ResNet-50 (no fc) 8.174, 2 FLOP/MAC
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+# Algorithmic HBM bytes of an average MFMA GEMM launch of this step (311 launches per step, 19.26 GFLOP each on average):
+# A + B read once (a 3x3 implicit-GEMM gather counts each source pixel once), C written once (fp32 for weight gradients).
+ALG_BYTES_PER_GEMM_LAUNCH = 54.27e6
 
 
 def synth_batch(B, S, vocab, device, seed):
@@ -62,6 +65,16 @@ def cpu_baseline(model, B, steps):
     dt = time.perf_counter() - t0
     return {"value": round(B * steps / dt, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": f"{steps} fp32 train steps (fwd+CE+bwd+clip+AdamW) of the CPU oracle at B={B}, S=128, 224x224 after 1 warm-up step"}
+
+
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json, produced by
+    tools/pmc_traffic.py on the GPU box; bench.py cannot run the profiler around itself). None when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["all_gemm"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def main():
@@ -117,17 +130,24 @@ def main():
     for _ in range(args.warmup):
         trainer.step(*batch)
     L = _lib.load()
-    sync()
-    if os.environ.get("MMSA_BENCH_NOPROF", "0") == "0":
-        L.mmsa_prof_begin(args.steps * 1200)
+    # (1) the timed region: exactly `steps` steps, un-instrumented (HIP events around every GEMM launch cost ~2 ms
+    #     per step, so they are kept out of the throughput number)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = trainer.step(*batch)
     sync()
     dt = time.perf_counter() - t0
+    # (2) the roofline pass: the same steps again with HIP events on the launch stream around every MFMA GEMM launch
+    psteps = min(args.steps, 5)
     ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-    L.mmsa_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+    if os.environ.get("MMSA_BENCH_NOPROF", "0") == "0":  # (skipped under rocprofv3, which times the kernels itself)
+        L.mmsa_prof_begin(psteps * 1200)
+        sync()
+        for _ in range(psteps):
+            trainer.step(*batch)
+        sync()
+        L.mmsa_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
     el = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -146,9 +166,11 @@ def main():
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": args.seq,
                        "image": "224x224x3", "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_bf16_kernel (all NT/NN/TN/implicit-conv launches of the timed steps)",
-                         "launches": n.value, "kernel_ms_per_step": round(ms.value / args.steps, 3),
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_GEMM_LAUNCH,
+                         "kernel": "gemm2_kernel / gemm_bf16_kernel: every MFMA GEMM launch (NT/NN/TN, implicit-GEMM "
+                                   "convolutions) of %d instrumented steps run right after the timed steps" % psteps,
+                         "launches": n.value, "kernel_ms_per_step": round(ms.value / psteps, 3),
                          "step_algorithmic_tflops_per_gpu": round(step_tflops, 2),
                          "step_frac_of_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4)},
             "loss": round(float(loss), 5),

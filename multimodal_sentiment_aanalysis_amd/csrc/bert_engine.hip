@@ -224,8 +224,9 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
     BertLayerWs& a = ws.L[l];
     const void* xin = l == 0 ? ws.x0 : ws.L[l - 1].out;
     void* ds2 = bB;
-    RET_IF(layernorm_bwd(c.dtype, dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, G(f.ln2w), G(f.ln2b), acc, ws.lnws, M, H, st));
-    RET_IF(e.bias_grad(ds2, H, G(f.b2), M, H, acc));
+    // ds2 is also dY of the FFN output Linear: its bias gradient (column sums of ds2) comes out of the same pass
+    RET_IF(layernorm_bwd(c.dtype, dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, G(f.ln2w), G(f.ln2b), acc, ws.lnws, M, H, st,
+                         G(f.b2)));
     RET_IF(e.linear_wgrad(ds2, H, a.act, I, G(f.w2), M, H, I, acc));
     void* dpre = ws.bufI;
     RET_IF(e.linear_dgrad(ds2, H, W(f.w2), dpre, I, M, H, I, a.pre, I));  // * gelu'(pre)
@@ -234,8 +235,8 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
     void* dh1 = bC;
     RET_IF(e.linear_dgrad(dpre, I, W(f.w1), dh1, H, M, I, H, nullptr, 0, ds2, H));  // + residual branch
     void* ds1 = dOut;
-    RET_IF(layernorm_bwd(c.dtype, dh1, a.s1, a.mean1, a.rstd1, P(f.ln1w), ds1, G(f.ln1w), G(f.ln1b), acc, ws.lnws, M, H, st));
-    RET_IF(e.bias_grad(ds1, H, G(f.bo), M, H, acc));
+    RET_IF(layernorm_bwd(c.dtype, dh1, a.s1, a.mean1, a.rstd1, P(f.ln1w), ds1, G(f.ln1w), G(f.ln1b), acc, ws.lnws, M, H, st,
+                         G(f.bo)));  // + bias gradient of the attention output Linear
     RET_IF(e.linear_wgrad(ds1, H, a.ctx, H, G(f.wo), M, H, H, acc));
     void* dctx = bB;
     RET_IF(e.linear_dgrad(ds1, H, W(f.wo), dctx, H, M, H, H));

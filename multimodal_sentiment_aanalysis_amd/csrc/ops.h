@@ -13,7 +13,8 @@ int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* bet
                   int M, int H, float eps, hipStream_t st);
 size_t layernorm_bwd_ws_bytes(int H);
 int layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                  void* dx, float* dgamma, float* dbeta, int accumulate, float* ws, int M, int H, hipStream_t st);
+                  void* dx, float* dgamma, float* dbeta, int accumulate, float* ws, int M, int H, hipStream_t st,
+                  float* dxsum = nullptr);
 size_t colsum_ws_bytes(int N);
 int colsum(int dtype, const void* x, long ldx, float* out, int accumulate, float* ws, int M, int N, hipStream_t st);
 int embed_gather(int dtype, const long long* ids, const void* word, const void* pos, const void* type, void* e, int M,

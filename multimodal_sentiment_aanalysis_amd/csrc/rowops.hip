@@ -58,19 +58,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma ; per-block partial dgamma/dbeta -> part[blk][2][H]
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma ; per-block partial dgamma/dbeta -> part[blk][NQ][H]
+// NQ = 3 adds the column sums of the stored dx: in BERT every LayerNorm input gradient is also the output gradient of
+// the Linear in front of it, so its bias gradient comes out of this pass instead of a separate column-sum launch pair.
 template <typename T, int NCH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(512) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, T* __restrict__ dx,
-                                                            float* __restrict__ part, int M, int H) {
-  extern __shared__ float lds[];  // [4 waves][2][H]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+                                                            float* __restrict__ part, int M, int H, int NQ) {
+  extern __shared__ float lds[];  // [NW waves][H], reused per quantity
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
   const int nch = H >> 2;
-  f32x4 ag[NCH], ab[NCH];
+  f32x4 ag[NCH], ab[NCH], ax[NCH];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) { ag[c] = f32x4{0, 0, 0, 0}; ab[c] = f32x4{0, 0, 0, 0}; }
-  for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
+  for (int c = 0; c < NCH; ++c) { ag[c] = f32x4{0, 0, 0, 0}; ab[c] = f32x4{0, 0, 0, 0}; ax[c] = f32x4{0, 0, 0, 0}; }
+  for (int row = blockIdx.x * NW + w; row < M; row += gridDim.x * NW) {
     const T* xr = x + (long)row * H;
     const T* dr = dy + (long)row * H;
     const float mu = mean[row], rs = rstd[row];
@@ -102,27 +104,50 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       if (ch < nch) {
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (gg[c][e] - s1 - xh[c][e] * s2);
+        for (int e = 0; e < 4; ++e) {
+          o[e] = rs * (gg[c][e] - s1 - xh[c][e] * s2);
+          ax[c][e] += q_f32<T>(o[e]);  // the value as stored (what a column sum over dx would read)
+        }
         Vec4<T>::store(oxr + ch * 4, o);
       }
     }
   }
-  // combine the 4 waves of the block, then write the block partial
+  // combine the waves of the block, one quantity at a time through [NW][H] floats of LDS, then write the block partial
+  for (int qn = 0; qn < NQ; ++qn) {
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int ch = lane + 64 * c;
-    if (ch < nch) {
-      *(f32x4*)(lds + (w * 2 + 0) * H + ch * 4) = ag[c];
-      *(f32x4*)(lds + (w * 2 + 1) * H + ch * 4) = ab[c];
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) *(f32x4*)(lds + w * H + ch * 4) = qn == 0 ? ag[c] : (qn == 1 ? ab[c] : ax[c]);
     }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += blockDim.x) {
+      float t = 0.f;
+      for (int ww = 0; ww < NW; ++ww) t += lds[ww * H + col];
+      part[((long)blockIdx.x * NQ + qn) * H + col] = t;
+    }
+    __syncthreads();
   }
+}
+
+// out_q[j] (+)= sum_b part[(b * nq + q) * n + j] for q < nq (up to 3 outputs in one launch; fixed order as below)
+__global__ __launch_bounds__(256) void partial_finalize_multi_kernel(const float* __restrict__ part, int nblk, int nq, int n,
+                                                                     float* __restrict__ out0, float* __restrict__ out1,
+                                                                     float* __restrict__ out2, int accumulate) {
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int jj = blockIdx.x * 16 + c;  // column of the [nq * n] wide partial rows
+  float t = 0.f;
+  if (jj < nq * n)
+    for (int b = r; b < nblk; b += 16) t += part[(long)b * nq * n + jj];
+  red[r][c] = t;
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * H; i += blockDim.x) {
-    const int which = i / H, col = i - which * H;
-    float t = 0.f;
-    for (int ww = 0; ww < 4; ++ww) t += lds[(ww * 2 + which) * H + col];
-    part[((long)blockIdx.x * 2 + which) * H + col] = t;
-  }
+  if (r != 0 || jj >= nq * n) return;
+  t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t += red[k][c];
+  const int q = jj / n, j = jj - q * n;
+  float* out = q == 0 ? out0 : (q == 1 ? out1 : out2);
+  out[j] = accumulate ? out[j] + t : t;
 }
 
 // out[j] (+)= scale * sum_b part[b * stride + j]  for j in [0, n)   (fixed order: bitwise reproducible)
@@ -177,25 +202,33 @@ int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* bet
   return MMSA_OK;
 }
 
-#define LN_BWD_BLOCKS 256
-size_t layernorm_bwd_ws_bytes(int H) { return (size_t)LN_BWD_BLOCKS * 2 * H * sizeof(float); }
+// one wave per row, 8 waves per workgroup, up to 512 workgroups (2 per CU = 16 waves per CU: with 256 x 4 waves the
+// kernel ran one wave per SIMD and streamed at 1.5 TB/s)
+#define LN_BWD_BLOCKS 512
+#define LN_BWD_WAVES 8
+size_t layernorm_bwd_ws_bytes(int H) { return (size_t)LN_BWD_BLOCKS * 3 * H * sizeof(float); }
 
+// dxsum (optional): column sums of the stored dx (+)= -> the bias gradient of the Linear that produced this LN's input
 int layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                  void* dx, float* dgamma, float* dbeta, int accumulate, float* ws, int M, int H, hipStream_t st) {
-  if (H % 4 || H > 2048) return MMSA_ERR_ARG;
-  const int grid = min(cdiv(M, 4), LN_BWD_BLOCKS);
-  const size_t lds = (size_t)8 * H * sizeof(float);
+                  void* dx, float* dgamma, float* dbeta, int accumulate, float* ws, int M, int H, hipStream_t st,
+                  float* dxsum) {
+  if (H % 4 || H > 2048) return MMSA_ERR_UNSUPPORTED;
+  const int nw = H > 1024 ? 4 : LN_BWD_WAVES;
+  const int grid = min(cdiv(M, nw), LN_BWD_BLOCKS);
+  const size_t lds = (size_t)nw * H * sizeof(float);
+  const int nq = dxsum ? 3 : 2;
   if (dtype == MMSA_BF16)
-    LN_DISPATCH(layernorm_bwd_kernel, bf16, H, dim3(grid), dim3(256), lds, st, (const bf16*)dy, (const bf16*)x, mean, rstd,
-                gamma, (bf16*)dx, ws, M, H);
+    LN_DISPATCH(layernorm_bwd_kernel, bf16, H, dim3(grid), dim3(64 * nw), lds, st, (const bf16*)dy, (const bf16*)x, mean, rstd,
+                gamma, (bf16*)dx, ws, M, H, nq);
   else
-    LN_DISPATCH(layernorm_bwd_kernel, float, H, dim3(grid), dim3(256), lds, st, (const float*)dy, (const float*)x, mean,
-                rstd, gamma, (float*)dx, ws, M, H);
+    LN_DISPATCH(layernorm_bwd_kernel, float, H, dim3(grid), dim3(64 * nw), lds, st, (const float*)dy, (const float*)x, mean,
+                rstd, gamma, (float*)dx, ws, M, H, nq);
   MMSA_CHECK_LAUNCH();
-  // partial layout is [blk][2][H]
-  int rc = partial_finalize(ws, grid, 2L * H, H, dgamma, accumulate, 1.f, st);
-  if (rc) return rc;
-  return partial_finalize(ws + H, grid, 2L * H, H, dbeta, accumulate, 1.f, st);
+  // partial layout is [blk][nq][H]: one launch finalizes every output
+  hipLaunchKernelGGL(partial_finalize_multi_kernel, dim3(cdiv(nq * H, 16)), dim3(256), 0, st, (const float*)ws, grid, nq, H,
+                     dgamma, dbeta, dxsum, accumulate);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
