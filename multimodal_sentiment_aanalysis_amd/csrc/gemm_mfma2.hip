@@ -509,20 +509,25 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
-  // the same 4 x NJ MFMAs with the NL LDS-DMA instructions of one K step spread between them (one after every second
-  // MFMA): issued in a burst right after the barrier by all 8 waves they queue in the address unit and every wave's
-  // MFMA stream stands still behind them
-  auto mma_half_dma = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[NJ], int stage) __attribute__((always_inline)) {
-    dma_begin();
+  // the same 4 x NJ MFMAs with half of the LDS-DMA instructions of a K step spread between them. The refill of the
+  // stage freed by the mid-step barrier of step u (= the DMA of step u+3) is issued in two parts: pieces 0..2 in the
+  // second half of step u (PART 0), the rest in the first half of step u+1 (PART 1). Issued as one burst right after
+  // the barrier by all 8 waves they queue in the address unit and every wave's MFMA stream stands still behind them.
+  constexpr int NLA = 3;  // pieces of part 0
+  auto mma_half_dma = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[NJ], int stage, auto part_c) __attribute__((always_inline)) {
+    constexpr int PART = decltype(part_c)::value;
+    constexpr int P0 = PART == 0 ? 0 : NLA, P1 = PART == 0 ? NLA : NL;  // pieces [P0, P1)
+    constexpr int GAP = (4 * NJ) / (P1 - P0 > 0 ? (P1 - P0) : 1);        // MFMAs between two DMA instructions
+    if constexpr (PART == 0) dma_begin();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
     auto one = [&](auto idx_c) __attribute__((always_inline)) {
       constexpr int idx = decltype(idx_c)::value;
       constexpr int i = idx / NJ, j = idx % NJ;
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-      if constexpr ((idx & 1) == 1 && idx / 2 < NL) {
+      if constexpr (idx % GAP == 1 % GAP && P0 + idx / GAP < P1) {
         __builtin_amdgcn_sched_barrier(0);
-        dma_piece(stage, std::integral_constant<int, idx / 2>{});
+        dma_piece(stage, std::integral_constant<int, P0 + idx / GAP>{});
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -538,13 +543,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       one(std::integral_constant<int, 12>{}); one(std::integral_constant<int, 13>{});
       one(std::integral_constant<int, 14>{}); one(std::integral_constant<int, 15>{});
     }
-    if constexpr (2 * NJ < NL) {  // NJ = 2: 8 MFMAs carry 4 pieces; the B piece(s) follow
-      dma_piece(stage, std::integral_constant<int, 4>{});
-      dma_piece(stage, std::integral_constant<int, 5>{});
-    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    dma_advance();
+    if constexpr (PART == 1) dma_advance();
   };
 
   // prologue: up to three steps of DMA in flight, then wait for step 0 and read its first-half fragments
@@ -559,38 +560,37 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   read_half(std::integral_constant<int, 0>{}, 0, a0, b0);
   if (s.dbg & 2) read_half(std::integral_constant<int, 1>{}, 0, a1, b1);
 
-  int eu1 = 0, eu2 = 0;  // store units of the counted epilogue that ended the previous step / the one before
+  int eu1 = 0;    // store units of the counted epilogue that ended the previous step
   int st = 0;     // u % 3
   for (int u = 0; u < total; ++u) {
     if (!(s.dbg & 2)) read_half(std::integral_constant<int, 1>{}, st, a1, b1);
     wait_lgkm<(RD_HALF < 14 ? RD_HALF : 14)>();  // first-half fragments (issued half a step ago) are in; 15 = "no wait"
     __builtin_amdgcn_sched_barrier(0);
-    mma_half(a0, b0);
+    // second part of the refill started in the previous step (the DMA of step u+2, into the stage of step u-1)
+    if (u >= 1 && u + 2 < total && !(s.dbg & 1)) mma_half_dma(a0, b0, st == 0 ? 2 : st - 1, std::integral_constant<int, 1>{});
+    else mma_half(a0, b0);
     __builtin_amdgcn_sched_barrier(0);
     const int nst = st == 2 ? 0 : st + 1;
     wait_lgkm<0>();  // second-half fragments are in (and every read of this stage is done: it may be refilled)
     __builtin_amdgcn_sched_barrier(0);
     if (u + 1 < total) {
-      {  // step u+1's DMA: allow the newer step's loads + the stores of counted epilogues issued after it
-        const int code = (u + 2 < total ? 5 : 0) + eu1 + eu2;
+      {  // step u+1's DMA: allow the newer step's loads (both parts are issued by now) + the stores of the counted
+         // epilogue of the previous step (the only one issued after the last part of step u+1's DMA)
+        const int code = (u + 2 < total ? 3 : 0) + eu1;
         switch (code) {
           case 0: wait_vm<0>(); break;
           case 1: wait_vm<NSU>(); break;
           case 2: wait_vm<2 * NSU>(); break;
-          case 3: wait_vm<3 * NSU>(); break;
-          case 4: wait_vm<4 * NSU>(); break;
-          case 5: wait_vm<NL>(); break;
-          case 6: wait_vm<NL + NSU>(); break;
-          case 7: wait_vm<NL + 2 * NSU>(); break;
-          case 8: wait_vm<NL + 3 * NSU>(); break;
-          default: wait_vm<NL + 4 * NSU>(); break;
+          case 3: wait_vm<NL>(); break;
+          case 4: wait_vm<NL + NSU>(); break;
+          default: wait_vm<NL + 2 * NSU>(); break;
         }
       }
       if (!(s.dbg & 4)) __builtin_amdgcn_s_barrier();
       if (!(s.dbg & 2)) read_half(std::integral_constant<int, 0>{}, nst, a0, b0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (u + 3 < total && !(s.dbg & 1)) mma_half_dma(a1, b1, st);
+    if (u + 3 < total && !(s.dbg & 1)) mma_half_dma(a1, b1, st, std::integral_constant<int, 0>{});
     else mma_half(a1, b1);
     int e = 0;
     if (++c_kt == C.nk) {
@@ -603,7 +603,6 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       c_item += G;
       if (c_item < s.items) C = decode(c_item);
     }
-    eu2 = eu1;
     eu1 = e;
     st = nst;
   }
