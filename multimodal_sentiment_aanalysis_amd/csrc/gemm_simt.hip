@@ -7,6 +7,7 @@
 // (every gather mode of gemm.h), which is what makes it a useful checker; it is not a performance kernel.
 #include "gemm.h"
 #include "gemm_epilogue.h"
+#include <type_traits>
 
 #define SBM 64
 #define SBN 64
@@ -57,8 +58,8 @@ __device__ __forceinline__ float simt_load_b(const GemmParams& p, int k, int n, 
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_simt_kernel(GemmParams p) {
-  __shared__ float As[SBK][SBM + 4];
-  __shared__ float Bs[SBK][SBN + 4];
+  __shared__ __attribute__((aligned(16))) float As[SBK][SBM + 4];
+  __shared__ __attribute__((aligned(16))) float Bs[SBK][SBN + 4];
   const int tid = threadIdx.x;
   const int ntn = (p.N + SBN - 1) / SBN;
   const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
@@ -77,7 +78,57 @@ __global__ __launch_bounds__(256) void gemm_simt_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
+  // fp32 plain (non-gather) operands with 16-byte aligned rows take 4 elements per load along their contiguous
+  // dimension (the fusion head's Linears: 57 launches per step, each a short serial K loop)
+  const bool vec = std::is_same<T, float>::value && p.gather == 0 && !(p.lda & 3) && !(p.ldb & 3) && !(p.K & 3) &&
+                   !(p.M & 3) && !(p.N & 3) && !(((size_t)p.A | (size_t)p.B) & 15);
   for (int k0 = kbeg; k0 < kend; k0 += SBK) {
+    if (vec) {
+      const float* A = (const float*)p.A;
+      const float* B = (const float*)p.B;
+      f32x4 va[2], vb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {  // 64 x 32 elements = 512 float4 per operand, 2 per thread
+        const int e = tid + 256 * i;
+        va[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        vb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.a_kmajor) {  // [K][M]: 16 float4 per k-row
+          const int kk = e >> 4, mm = (e & 15) * 4;
+          if (k0 + kk < kend && m0 + mm < p.M) va[i] = *(const f32x4*)(A + (long)(k0 + kk) * p.lda + m0 + mm);
+        } else {           // [M][K]: 8 float4 per row
+          const int mm = e >> 3, kk = (e & 7) * 4;
+          if (k0 + kk < kend && m0 + mm < p.M) va[i] = *(const f32x4*)(A + (long)(m0 + mm) * p.lda + k0 + kk);
+        }
+        if (p.b_kmajor) {
+          const int kk = e >> 4, nn = (e & 15) * 4;
+          if (k0 + kk < kend && n0 + nn < p.N) vb[i] = *(const f32x4*)(B + (long)(k0 + kk) * p.ldb + n0 + nn);
+        } else {
+          const int nn = e >> 3, kk = (e & 7) * 4;
+          if (k0 + kk < kend && n0 + nn < p.N) vb[i] = *(const f32x4*)(B + (long)(n0 + nn) * p.ldb + k0 + kk);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = tid + 256 * i;
+        if (p.a_kmajor) {
+          const int kk = e >> 4, mm = (e & 15) * 4;
+          *(f32x4*)&As[kk][mm] = va[i];
+        } else {
+          const int mm = e >> 3, kk = (e & 7) * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) As[kk + r][mm] = va[i][r];
+        }
+        if (p.b_kmajor) {
+          const int kk = e >> 4, nn = (e & 15) * 4;
+          *(f32x4*)&Bs[kk][nn] = vb[i];
+        } else {
+          const int nn = e >> 3, kk = (e & 7) * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Bs[kk + r][nn] = vb[i][r];
+        }
+      }
+    } else {
+
     // 64x16 elements per operand, 4 per thread. Pick the thread->element map so global reads are coalesced
     // along the contiguous dimension of each storage form.
     float ta[SBK / 4], tb[SBK / 4];
@@ -100,6 +151,7 @@ __global__ __launch_bounds__(256) void gemm_simt_kernel(GemmParams p) {
       int nn, kb;
       if (p.b_kmajor) { nn = e & 63; kb = e >> 6; } else { kb = e & (SBK - 1); nn = e / SBK; }
       Bs[kb][nn] = tb[i];
+    }
     }
     __syncthreads();
 #pragma unroll
