@@ -86,22 +86,26 @@ __device__ __forceinline__ bf16x8 lds_rd_tr(unsigned addr) {  // k rows kb..kb+3
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int NJ, bool A_KM, bool B_KM, int GATHER>
+// WM = wave rows: 4 -> 256-row tile, waves 4(M) x 2(N); 2 -> 128-row tile, waves 2(M) x 4(N) (twice the tiles for
+// the mid-size convolutions: M = 12544 / 3136 gives only 49 / 13 row tiles of 256). NJ = 16-column MFMA tiles per wave:
+// BN = NJ * 16 * (8 / WM).
+template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) {
   // The body is compiled in the device pass only: hipcc's HOST pass (ROCm 7.2) silently fails to instantiate this
   // template when it sees the body (no diagnostic, the launch stub stays an undefined symbol of the .so).
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BN = NJ * 32;
-  constexpr int NLB = (NJ == 2 && !B_KM) ? 1 : 2;  // B LDS-DMA pieces per wave per step
-  constexpr int NL = 4 + NLB;                      // LDS-DMA instructions per wave per step
+  constexpr int WN = 8 / WM, BM = WM * 64, BN = NJ * 16 * WN;
+  constexpr int NPA = BM / 64;  // A LDS-DMA pieces per wave per step (a piece = 1 KiB = 8 rows)
+  constexpr int NLB = (BN <= 64 && !B_KM) ? 1 : 2;  // B LDS-DMA pieces per wave per step
+  constexpr int NL = NPA + NLB;                      // LDS-DMA instructions per wave per step
   // store instructions per wave per plain epilogue, in units of 2 NJ: bf16 output = 1 unit (16 B per lane, row tiles
   // paired), fp32 output / split-K slabs = 2 units. The counted waits need the exact number.
   constexpr int NSU = 2 * NJ;
   constexpr int OOB = (int)0x80000000;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WM == 4 ? wave >> 1 : wave >> 2, wn = WM == 4 ? wave & 1 : wave & 3;
 
   // ---- logical workgroup id: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of items
   const int G = gridDim.x;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     const int tile = item - sp * s.ntiles;
     const int tm = (int)fd_div((uint32_t)tile, s.fd_ntn);
     const int tn = tile - tm * s.ntn;
-    it.m0 = tm * G2_BM; it.n0 = tn * BN; it.sp = sp;
+    it.m0 = tm * BM; it.n0 = tn * BN; it.sp = sp;
     it.kb = sp * s.per;
     it.nk = min(s.per, s.nsteps - it.kb);
     return it;
@@ -135,15 +139,15 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   // source offset of a row changes with the tap, so it is recomputed per K step from the row's decomposed pixel;
   // GATHER 2 = the k-major B rows (k) are output pixels and the columns are (tap, channel): the pixel of a lane's k-row
   // is decomposed per K step. A K step never straddles a tap (cper % 64 == 0 is checked by the launcher).
-  int relA[4], rcA[4], relB[NLB], rcB[NLB];  // rc = row (k-contiguous) or first column (k-major) inside the tile
+  int relA[NPA], rcA[NPA], relB[NLB], rcB[NLB];  // rc = row (k-contiguous) or first column (k-major) inside the tile
   int krowB[NLB];                            // GATHER 2: k-row of the lane's B chunk inside a K step
   const int kc8 = ((lane & 7) ^ (lane >> 3)) * 8;
   {
     const int kc = (lane & 7) ^ (lane >> 3);
     const int pc = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pi = wave * 4 + i;
+    for (int i = 0; i < NPA; ++i) {
+      const int pi = wave * NPA + i;
       if constexpr (!A_KM) {
         rcA[i] = pi * 8 + (lane >> 3);
         relA[i] = (int)(((long)rcA[i] * p.lda + kc * 8) * 2);
@@ -177,12 +181,12 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   // ---- loader cursor
   int l_item = lb, l_kt = 0;
   Item L = decode(l_item);
-  int voffA[4], voffB[NLB];
-  RowPix a_pix[4];                       // GATHER 1: decomposed pixel of the lane's 4 A rows of the current tile
+  int voffA[NPA], voffB[NLB];
+  RowPix a_pix[NPA];                       // GATHER 1: decomposed pixel of the lane's 4 A rows of the current tile
   int b_ky[NLB], b_kx[NLB], b_coff[NLB];  // GATHER 2: tap and channel offset of the lane's B column chunks
   auto loader_setup = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPA; ++i) {
       if constexpr (GATHER == 1) a_pix[i] = decompose_pixel(p.g, L.m0 + rcA[i], p.M);
       else voffA[i] = (L.m0 + rcA[i] < p.M) ? relA[i] : OOB;
     }
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       const int c0 = k0 - (int)tap * p.g.cper;
       const int ky = (int)fd_div(tap, p.g.fd_kw), kx = (int)tap - ky * p.g.KW;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NPA; ++i) {
         const long src = tap_src(p.g, a_pix[i], ky, kx);
         voffA[i] = src >= 0 ? (int)((src + kc8) * 2) : OOB;
       }
@@ -235,12 +239,12 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   };
   auto dma_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_c)::value;
-    if constexpr (pc < 4) {
-      unsigned char* sa = smem + stage * G2_STAGE + wave * 4096 + pc * 1024;
+    if constexpr (pc < NPA) {
+      unsigned char* sa = smem + stage * G2_STAGE + wave * (NPA * 1024) + pc * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)sa, 16, voffA[pc], d_soffA, 0, 0);
     } else if constexpr (pc < NL) {
-      unsigned char* sb = smem + stage * G2_STAGE + G2_A_BYTES + wave * (NLB * 1024) + (pc - 4) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)sb, 16, voffB[pc - 4], d_soffB, 0, 0);
+      unsigned char* sb = smem + stage * G2_STAGE + G2_A_BYTES + wave * (NLB * 1024) + (pc - NPA) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)sb, 16, voffB[pc - NPA], d_soffB, 0, 0);
     }
   };
   auto dma_advance = [&]() __attribute__((always_inline)) {
@@ -492,11 +496,13 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     }
     if constexpr (!B_KM) {
       const unsigned b = offB[kk] + so;
-      fb[0] = lds_rd128<0>(b); fb[1] = lds_rd128<2048>(b);
+      fb[0] = lds_rd128<0>(b);
+      if constexpr (NJ > 1) fb[1] = lds_rd128<2048>(b);
       if constexpr (NJ > 2) fb[2] = lds_rd128<4096>(b);
       if constexpr (NJ > 3) fb[3] = lds_rd128<6144>(b);
     } else {
-      fb[0] = lds_rd_tr<kk * 8192>(offB[0] + so); fb[1] = lds_rd_tr<kk * 8192>(offB[1] + so);
+      fb[0] = lds_rd_tr<kk * 8192>(offB[0] + so);
+      if constexpr (NJ > 1) fb[1] = lds_rd_tr<kk * 8192>(offB[1] + so);
       if constexpr (NJ > 2) fb[2] = lds_rd_tr<kk * 8192>(offB[2] + so);
       if constexpr (NJ > 3) fb[3] = lds_rd_tr<kk * 8192>(offB[3] + so);
     }
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   // stage freed by the mid-step barrier of step u (= the DMA of step u+3) is issued in two parts: pieces 0..2 in the
   // second half of step u (PART 0), the rest in the first half of step u+1 (PART 1). Issued as one burst right after
   // the barrier by all 8 waves they queue in the address unit and every wave's MFMA stream stands still behind them.
-  constexpr int NLA = 3;  // pieces of part 0
+  constexpr int NLA = (NL + 1) / 2;  // pieces of part 0
   auto mma_half_dma = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[NJ], int stage, auto part_c) __attribute__((always_inline)) {
     constexpr int PART = decltype(part_c)::value;
     constexpr int P0 = PART == 0 ? 0 : NLA, P1 = PART == 0 ? NLA : NL;  // pieces [P0, P1)
@@ -533,8 +539,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     };
     one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
     one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
-    one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
-    one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+    if constexpr (NJ > 1) {
+      one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+      one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+    }
     if constexpr (NJ > 2) {
       one(std::integral_constant<int, 8>{}); one(std::integral_constant<int, 9>{});
       one(std::integral_constant<int, 10>{}); one(std::integral_constant<int, 11>{});
@@ -660,20 +668,26 @@ bool gemm2_eligible(const GemmParams& p) {
   return true;
 }
 
-struct G2Plan { int nj, split; };
+struct G2Plan { int wm, nj, split; };  // wave rows (4: 256-row tile, 2: 128-row tile), column tiles per wave, K split
+static inline int g2_bm(const G2Plan& pl) { return pl.wm * 64; }
+static inline int g2_bn(const G2Plan& pl) { return pl.nj * 16 * (8 / pl.wm); }
 
-// Tile width and K split. Cost model in microseconds, calibrated on MI355X (profiles/): a K step of the 256-row tile
+// Tile shape and K split. Cost model in microseconds, calibrated on MI355X (profiles/): a K step of the 256-row tile
 // costs about the same for every width (the 32 KiB A tile, the barrier and the LDS traffic dominate; MFMA-only time is
 // 0.19 us per 32 columns): t_step = 1.0 + 0.06 nj; per item 0.3 + 0.2 nj (pipeline bubble + epilogue stores);
-// a split adds the slab round trip at ~4 TB/s and the reducer launch. So: the widest tile that keeps whole rounds of
+// the 128-row tile moves 2/3 of the bytes and half of the MFMAs per step: t_step = 0.72 + 0.06 nj per 64 columns;
+// a split adds the slab round trip at ~4 TB/s and the reducer launch. So: the biggest tile that keeps whole rounds of
 // `cus` workgroups busy, and as many K slices as it takes to fill the chip when there are few tiles (weight
 // gradients: 1..72 tiles with K = 8192..802816).
 static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail) {
-  const int ntm = cdiv(p.M, G2_BM), nsteps = p.K / G2_BK;
-  G2Plan best{4, 1};
+  const int nsteps = p.K / G2_BK;
+  G2Plan best{4, 4, 1};
   double best_cost = 1e300;
-  for (int nj = 4; nj >= 2; --nj) {
-    const int bn = nj * 32, ntn = cdiv(p.N, bn);
+  static const int cfgs[5][2] = {{4, 4}, {4, 3}, {4, 2}, {2, 2}, {2, 1}};
+  for (int ci = 0; ci < 5; ++ci) {
+    const G2Plan shape{cfgs[ci][0], cfgs[ci][1], 1};
+    const int bm = g2_bm(shape), bn = g2_bn(shape);
+    const int ntm = cdiv(p.M, bm), ntn = cdiv(p.N, bn);
     const long tiles = (long)ntm * ntn;
     int smax = 1;
     if (ws_bytes_avail > 0 && p.ws) {
@@ -691,8 +705,10 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
       for (long d = sp; d <= sp + 1; ++d)
         if (d > 1 && d <= smax && nc < 16) cand[nc++] = (int)d;
     }
-    const double t_step = 1.0 + 0.06 * nj, t_item = 0.3 + 0.2 * nj;
-    const double waste = (double)ntn * bn / p.N;  // padded columns: only as a tie breaker
+    const int w32 = bn / 32;  // tile width in 32-column units
+    const double t_step = shape.wm == 4 ? 1.0 + 0.06 * w32 : 0.72 + 0.05 * w32;
+    const double t_item = shape.wm == 4 ? 0.3 + 0.2 * w32 : 0.3 + 0.1 * w32;
+    const double waste = (double)ntn * bn / p.N * ((double)ntm * bm / p.M);  // padding: only as a tie breaker
     for (int c = 0; c < nc; ++c) {
       const int per = cdiv(nsteps, cand[c]);
       const int split = cdiv(nsteps, per);  // no empty slices: e.g. 3136 steps / 256 -> 13 per slice -> 242 slices
@@ -700,7 +716,7 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
       const long rounds = (items + cus - 1) / cus;
       double cost = (double)rounds * (per * t_step + t_item) + 1e-3 * waste;
       if (split > 1) cost += 3.0 + 2.0 * split * (double)p.M * p.N * 4.0 / 4e6;
-      if (cost < best_cost - 1e-9) { best_cost = cost; best = G2Plan{nj, split}; }
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = G2Plan{shape.wm, shape.nj, split}; }
     }
   }
   return best;
@@ -717,30 +733,30 @@ static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
   return plan;
 }
 
-template <int NJ, bool A_KM, bool B_KM, int GATHER>
+template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER>
 static int g2_launch_t(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<NJ, A_KM, B_KM, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              G2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm2_kernel<NJ, A_KM, B_KM, GATHER>), dim3(grid), dim3(512), G2_LDS, st, p, s);
+  hipLaunchKernelGGL((gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER>), dim3(grid), dim3(512), G2_LDS, st, p, s);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
 
-template <int NJ>
+template <int WM, int NJ>
 static int g2_launch_nj(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
   if (p.gather == 1) {
-    if (!p.b_kmajor) return g2_launch_t<NJ, false, false, 1>(p, s, grid, st);
-    return g2_launch_t<NJ, false, true, 1>(p, s, grid, st);
+    if (!p.b_kmajor) return g2_launch_t<WM, NJ, false, false, 1>(p, s, grid, st);
+    return g2_launch_t<WM, NJ, false, true, 1>(p, s, grid, st);
   }
-  if (p.gather == 2) return g2_launch_t<NJ, true, true, 2>(p, s, grid, st);
-  if (!p.a_kmajor && !p.b_kmajor) return g2_launch_t<NJ, false, false, 0>(p, s, grid, st);
-  if (!p.a_kmajor && p.b_kmajor) return g2_launch_t<NJ, false, true, 0>(p, s, grid, st);
-  if (p.a_kmajor && p.b_kmajor) return g2_launch_t<NJ, true, true, 0>(p, s, grid, st);
-  return g2_launch_t<NJ, true, false, 0>(p, s, grid, st);
+  if (p.gather == 2) return g2_launch_t<WM, NJ, true, true, 2>(p, s, grid, st);
+  if (!p.a_kmajor && !p.b_kmajor) return g2_launch_t<WM, NJ, false, false, 0>(p, s, grid, st);
+  if (!p.a_kmajor && p.b_kmajor) return g2_launch_t<WM, NJ, false, true, 0>(p, s, grid, st);
+  if (p.a_kmajor && p.b_kmajor) return g2_launch_t<WM, NJ, true, true, 0>(p, s, grid, st);
+  return g2_launch_t<WM, NJ, true, false, 0>(p, s, grid, st);
 }
 
 // p.split_k on entry: 1 = no split wanted; > 1 = upper bound chosen by the caller (needs p.ws with room for it)
@@ -750,15 +766,21 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   if (p.split_k < 1) p.split_k = 1;
   if (p.split_k > 1 && !p.ws) return MMSA_ERR_ARG;
   G2Plan plan = g2_plan(p, cus, ws_bytes_avail);
-  if (const char* f = getenv("MMSA_G2_NJ")) { const int v = atoi(f); if (v >= 2 && v <= 4) plan.nj = v; }
+  if (const char* f = getenv("MMSA_G2_NJ")) {  // test hook: "nj" (256-row tile) or "wm:nj"
+    int a = 0, b = 0;
+    const int n = sscanf(f, "%d:%d", &a, &b);
+    if (n == 2 && (a == 4 || a == 2) && b >= 1 && b <= (a == 4 ? 4 : 2) && !(a == 4 && b < 2)) { plan.wm = a; plan.nj = b; }
+    else if (n == 1 && a >= 2 && a <= 4) { plan.wm = 4; plan.nj = a; }
+  }
   const long slab_bytes = (long)plan.split * p.M * p.N * 4;
   if (plan.split > 1 && slab_bytes >= 0x7FFFFFF0L) plan.split = 1;
   G2Sched s;
-  const int bn = plan.nj * 32;
-  s.ntm = cdiv(p.M, G2_BM); s.ntn = cdiv(p.N, bn); s.ntiles = s.ntm * s.ntn;
+  const int bm = g2_bm(plan), bn = g2_bn(plan);
+  s.ntm = cdiv(p.M, bm); s.ntn = cdiv(p.N, bn); s.ntiles = s.ntm * s.ntn;
   s.nsteps = p.K / G2_BK;
   s.split_k = plan.split;
   s.per = cdiv(s.nsteps, s.split_k);
+  s.split_k = cdiv(s.nsteps, s.per);
   s.items = s.ntiles * s.split_k;
   s.fd_ntiles = make_fastdiv((uint32_t)s.ntiles);
   s.fd_ntn = make_fastdiv((uint32_t)s.ntn);
@@ -778,9 +800,14 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   }
   const int grid = (int)(s.items < cus ? s.items : cus);
   int rc;
-  if (plan.nj == 4) rc = g2_launch_nj<4>(p, s, grid, st);
-  else if (plan.nj == 3) rc = g2_launch_nj<3>(p, s, grid, st);
-  else rc = g2_launch_nj<2>(p, s, grid, st);
+  if (plan.wm == 4) {
+    if (plan.nj == 4) rc = g2_launch_nj<4, 4>(p, s, grid, st);
+    else if (plan.nj == 3) rc = g2_launch_nj<4, 3>(p, s, grid, st);
+    else rc = g2_launch_nj<4, 2>(p, s, grid, st);
+  } else {
+    if (plan.nj == 2) rc = g2_launch_nj<2, 2>(p, s, grid, st);
+    else rc = g2_launch_nj<2, 1>(p, s, grid, st);
+  }
   if (rc) return rc;
   if (s.split_k > 1) {
     launch_splitk_reduce<bf16>(p, st);

@@ -2,7 +2,7 @@
 
 The kernel's hazards are ordering hazards (counted vmcnt waits, one barrier per K step, prefetch across tile
 boundaries), so the cases are chosen to walk every schedule shape: one K step per tile (K = 64), many tiles per
-workgroup (> 256 items), ragged M / N edges, every tile width (MMSA_G2_NJ = 2 / 3 / 4), all four operand layouts,
+workgroup (> 256 items), ragged M / N edges, every tile shape (MMSA_G2_NJ = 2 / 3 / 4 for the 256-row tile, 2:1 / 2:2 for the 128-row tile), all four operand layouts,
 split-K slabs, plain and memory-reading epilogues, and the BERT-base shapes at full size. The reference is a
 float32 matmul of the same bf16-rounded operands (torch, on the device); tolerance = bf16 output rounding.
 """
@@ -57,7 +57,7 @@ SHAPES = [  # M, N, K
 ]
 
 
-@pytest.mark.parametrize("nj", [0, 2, 3, 4])
+@pytest.mark.parametrize("nj", [0, 2, 3, 4, "2:1", "2:2"])
 @pytest.mark.parametrize("M,N,Kd", SHAPES)
 def test_g2_nt(dev, M, N, Kd, nj):
     A = rnd((M, Kd), dev, 1)
@@ -68,7 +68,7 @@ def test_g2_nt(dev, M, N, Kd, nj):
     close(C, A.float() @ B.float().T, f"NT nj={nj}")
 
 
-@pytest.mark.parametrize("nj", [0, 2, 3, 4])
+@pytest.mark.parametrize("nj", [0, 2, 3, 4, "2:1", "2:2"])
 @pytest.mark.parametrize("M,N,Kd", [(8192, 768, 3072), (50000, 64, 256), (1000, 200, 192), (8192, 3072, 768)])
 def test_g2_nn(dev, M, N, Kd, nj):
     A = rnd((M, Kd), dev, 1)
@@ -79,7 +79,7 @@ def test_g2_nn(dev, M, N, Kd, nj):
     close(C, A.float() @ B.float(), f"NN nj={nj}")
 
 
-@pytest.mark.parametrize("nj", [0, 2, 3, 4])
+@pytest.mark.parametrize("nj", [0, 2, 3, 4, "2:1", "2:2"])
 @pytest.mark.parametrize("M,N,Kd,split", [(768, 3072, 8192, 8), (64, 576, 200704, 64), (256, 64, 50176, 32),
                                           (136, 264, 1024, 1), (2304, 768, 8192, 4), (64, 64, 6400, 16)])
 def test_g2_tn_f32(dev, M, N, Kd, split, nj):
@@ -99,7 +99,7 @@ def test_g2_tn_f32(dev, M, N, Kd, split, nj):
     close(C2.double(), A.double().T @ B.double(), f"TN overwrite nj={nj}", tol=2e-5)
 
 
-@pytest.mark.parametrize("nj", [0, 2, 3, 4])
+@pytest.mark.parametrize("nj", [0, 2, 3, 4, "2:1", "2:2"])
 def test_g2_tn_kcontig_b(dev, nj):
     M, N, Kd = 520, 264, 192
     A = rnd((Kd, M), dev, 1)
@@ -110,7 +110,7 @@ def test_g2_tn_kcontig_b(dev, nj):
     close(C, A.float().T @ B.float().T, f"TN/kc nj={nj}")
 
 
-@pytest.mark.parametrize("nj", [0, 3])
+@pytest.mark.parametrize("nj", [0, 3, "2:2"])
 @pytest.mark.parametrize("M,N,Kd", [(8192, 3072, 768), (700, 200, 128)])
 def test_g2_epilogues(dev, M, N, Kd, nj):
     A = rnd((M, Kd), dev, 1, 0.3)
@@ -149,7 +149,7 @@ CONVS = [  # B, H, W, Cin, Cout, k, stride, pad — large enough for many tiles 
 ]
 
 
-@pytest.mark.parametrize("nj", [0, 2, 3])
+@pytest.mark.parametrize("nj", [0, 2, 3, "2:1", "2:2"])
 @pytest.mark.parametrize("cfg", CONVS)
 def test_g2_conv(dev, cfg, nj):
     B, H, W, Cin, Cout, k, s, p = cfg
