@@ -72,43 +72,107 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const T* __restrict_
   f32x4 ag[NCH], ab[NCH], ax[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) { ag[c] = f32x4{0, 0, 0, 0}; ab[c] = f32x4{0, 0, 0, 0}; ax[c] = f32x4{0, 0, 0, 0}; }
-  for (int row = blockIdx.x * NW + w; row < M; row += gridDim.x * NW) {
-    const T* xr = x + (long)row * H;
-    const T* dr = dy + (long)row * H;
-    const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[NCH], gg[NCH];
-    float s1 = 0.f, s2 = 0.f;
+  // two rows per iteration: both rows' loads are issued before either row's reductions (two memory round trips in
+  // flight per wave instead of a serial load -> reduce -> store chain); written out twice, not as lambdas over the
+  // accumulator arrays, which hipcc moved to scratch
+  const int rstride = gridDim.x * NW;
+  for (int rowb = blockIdx.x * NW + w; rowb < M; rowb += 2 * rstride) {
+    const int rowA = rowb;
+    const bool okA = rowA < M;
+    const T* xrA = x + (long)(okA ? rowA : 0) * H;
+    const T* drA = dy + (long)(okA ? rowA : 0) * H;
+    const float muA = mean[okA ? rowA : 0], rsA = rstd[okA ? rowA : 0];
+    f32x4 xvA[NCH], dvA[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + 64 * c;
-      if (ch < nch) {
-        const f32x4 xv = Vec4<T>::load(xr + ch * 4), dv = Vec4<T>::load(dr + ch * 4);
+      xvA[c] = f32x4{0, 0, 0, 0}; dvA[c] = f32x4{0, 0, 0, 0};
+      if (ch < nch && okA) { xvA[c] = Vec4<T>::load(xrA + ch * 4); dvA[c] = Vec4<T>::load(drA + ch * 4); }
+    }
+    const int rowB = rowb + rstride;
+    const bool okB = rowB < M;
+    const T* xrB = x + (long)(okB ? rowB : 0) * H;
+    const T* drB = dy + (long)(okB ? rowB : 0) * H;
+    const float muB = mean[okB ? rowB : 0], rsB = rstd[okB ? rowB : 0];
+    f32x4 xvB[NCH], dvB[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      xvB[c] = f32x4{0, 0, 0, 0}; dvB[c] = f32x4{0, 0, 0, 0};
+      if (ch < nch && okB) { xvB[c] = Vec4<T>::load(xrB + ch * 4); dvB[c] = Vec4<T>::load(drB + ch * 4); }
+    }
+    f32x4 xhA[NCH], ggA[NCH];
+    float s1A = 0.f, s2A = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      xhA[c] = f32x4{0, 0, 0, 0}; ggA[c] = f32x4{0, 0, 0, 0};
+      if (ch < nch && okA) {
         const f32x4 g = *(const f32x4*)(gamma + ch * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          xh[c][e] = (xv[e] - mu) * rs;
-          gg[c][e] = dv[e] * g[e];
-          s1 += gg[c][e];
-          s2 += gg[c][e] * xh[c][e];
-          ag[c][e] += dv[e] * xh[c][e];
-          ab[c][e] += dv[e];
+          xhA[c][e] = (xvA[c][e] - muA) * rsA;
+          ggA[c][e] = dvA[c][e] * g[e];
+          s1A += ggA[c][e];
+          s2A += ggA[c][e] * xhA[c][e];
+          ag[c][e] += dvA[c][e] * xhA[c][e];
+          ab[c][e] += dvA[c][e];
         }
       }
     }
-    s1 = wave_sum(s1) / (float)H;
-    s2 = wave_sum(s2) / (float)H;
-    T* oxr = dx + (long)row * H;
+    f32x4 xhB[NCH], ggB[NCH];
+    float s1B = 0.f, s2B = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + 64 * c;
-      if (ch < nch) {
-        f32x4 o;
+      xhB[c] = f32x4{0, 0, 0, 0}; ggB[c] = f32x4{0, 0, 0, 0};
+      if (ch < nch && okB) {
+        const f32x4 g = *(const f32x4*)(gamma + ch * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          o[e] = rs * (gg[c][e] - s1 - xh[c][e] * s2);
-          ax[c][e] += q_f32<T>(o[e]);  // the value as stored (what a column sum over dx would read)
+          xhB[c][e] = (xvB[c][e] - muB) * rsB;
+          ggB[c][e] = dvB[c][e] * g[e];
+          s1B += ggB[c][e];
+          s2B += ggB[c][e] * xhB[c][e];
+          ag[c][e] += dvB[c][e] * xhB[c][e];
+          ab[c][e] += dvB[c][e];
         }
-        Vec4<T>::store(oxr + ch * 4, o);
+      }
+    }
+    s1A = wave_sum(s1A) / (float)H;
+    s2A = wave_sum(s2A) / (float)H;
+    if (okA) {
+      T* oxr = dx + (long)rowA * H;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = rsA * (ggA[c][e] - s1A - xhA[c][e] * s2A);
+            ax[c][e] += q_f32<T>(o[e]);  // the value as stored (what a column sum over dx would read)
+          }
+          Vec4<T>::store(oxr + ch * 4, o);
+        }
+      }
+    }
+    s1B = wave_sum(s1B) / (float)H;
+    s2B = wave_sum(s2B) / (float)H;
+    if (okB) {
+      T* oxr = dx + (long)rowB * H;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = rsB * (ggB[c][e] - s1B - xhB[c][e] * s2B);
+            ax[c][e] += q_f32<T>(o[e]);  // the value as stored (what a column sum over dx would read)
+          }
+          Vec4<T>::store(oxr + ch * 4, o);
+        }
       }
     }
   }
