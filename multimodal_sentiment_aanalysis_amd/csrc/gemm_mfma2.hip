@@ -41,6 +41,8 @@ struct G2Sched {
   int fast;              // epilogue is a plain store (no memory reads): exact store counting
   FastDiv fd_ntiles, fd_ntn;
   unsigned c_bytes;      // byte extent of the output view (C, or the split-K slabs)
+  int rb, cb;            // 2-D blocking of the tile order (rb x cb tiles = one XCD's round), 0 = row-major
+  FastDiv fd_cb, fd_sbc;  // divisors: cb, super-blocks per row of super-blocks
   int dbg;               // timing-only ablations (MMSA_G2_DBG bitmask; results are wrong): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no epilogue
 };
 
@@ -122,8 +124,18 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     Item it;
     const int sp = (int)fd_div((uint32_t)item, s.fd_ntiles);
     const int tile = item - sp * s.ntiles;
-    const int tm = (int)fd_div((uint32_t)tile, s.fd_ntn);
-    const int tn = tile - tm * s.ntn;
+    int tm, tn;
+    if (s.rb > 0) {  // super-blocks of rb x cb tiles (32 tiles = the run one XCD works on in a round): the XCD's L2 then
+                     // holds rb A panels + cb B panels per K step instead of ~1 + ntn (B re-fetched by every XCD)
+      const int sb = tile >> 5, within = tile & 31;
+      const int r = (int)fd_div((uint32_t)within, s.fd_cb), c = within - r * s.cb;
+      const int sbr = (int)fd_div((uint32_t)sb, s.fd_sbc), sbc = sb - sbr * (int)s.fd_sbc.d;
+      tm = sbr * s.rb + r;
+      tn = sbc * s.cb + c;
+    } else {
+      tm = (int)fd_div((uint32_t)tile, s.fd_ntn);
+      tn = tile - tm * s.ntn;
+    }
     it.m0 = tm * BM; it.n0 = tn * BN; it.sp = sp;
     it.kb = sp * s.per;
     it.nk = min(s.per, s.nsteps - it.kb);
@@ -784,6 +796,29 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   s.items = s.ntiles * s.split_k;
   s.fd_ntiles = make_fastdiv((uint32_t)s.ntiles);
   s.fd_ntn = make_fastdiv((uint32_t)s.ntn);
+  s.rb = 0; s.cb = 0;
+  s.fd_cb = make_fastdiv(1); s.fd_sbc = make_fastdiv(1);
+  {
+    // Opt-in (MMSA_G2_2D=1): measured on MI355X it changes neither the stand-alone GEMM times nor the step (the CUs of
+    // an XCD walk K in lock-step, so whoever shares a panel waits for the same fill either way); it only lowers the
+    // L2-miss traffic that the Infinity Cache absorbs.
+    static const bool no2d = [] { const char* v = getenv("MMSA_G2_2D"); return !(v && atoi(v) != 0); }();
+    // 2-D blocking when it lowers (2 rb + cb): A panel = 32 KiB, B panel = 16 KiB per K step and XCD
+    int best_cb = 0;
+    double best = 2.0 * 32.0 / s.ntn + s.ntn;  // row-major: a run of 32 tiles spans 32/ntn rows and all ntn columns
+    if (s.ntn >= 32) best = 2.0 + 32.0;
+    for (int cb = 2; cb <= 16; cb <<= 1) {
+      const int rb = 32 / cb;
+      if (s.ntn % cb || s.ntm % rb) continue;
+      const double c = 2.0 * rb + cb;
+      if (c < best - 1e-9) { best = c; best_cb = cb; }
+    }
+    if (best_cb && !no2d && cus == 256) {
+      s.cb = best_cb; s.rb = 32 / best_cb;
+      s.fd_cb = make_fastdiv((uint32_t)s.cb);
+      s.fd_sbc = make_fastdiv((uint32_t)(s.ntn / s.cb));
+    }
+  }
   s.fast = (!p.bias && !p.C2 && p.act == MMSA_ACT_NONE && !p.mul && !p.add && !(p.out_f32 && p.accumulate)) ? 1 : 0;
   p.split_k = s.split_k;
   s.dbg = 0;
