@@ -156,15 +156,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     for (int e = 0; e < 4; ++e) { v.lo[e] = apply_act(v.lo[e], act); v.hi[e] = apply_act(v.hi[e], act); }
     Vec8<T>::store(y + r * C + col, v);
   };
-  long r = (long)blockIdx.x * rlanes + rl;
-  for (; r + stride < M; r += 2 * stride) {  // two rows in flight per lane
-    const f32x8 x0 = Vec8<T>::load(x + r * C + col), x1 = Vec8<T>::load(x + (r + stride) * C + col);
-    f32x8 q0 = zero8(), q1 = zero8();
-    if (res) { q0 = Vec8<T>::load(res + r * C + col); q1 = Vec8<T>::load(res + (r + stride) * C + col); }
-    one(r, x0, q0);
-    one(r + stride, x1, q1);
-  }
-  for (; r < M; r += stride) {
+  for (long r = (long)blockIdx.x * rlanes + rl; r < M; r += stride) {
     const f32x8 x0 = Vec8<T>::load(x + r * C + col);
     f32x8 q0 = zero8();
     if (res) q0 = Vec8<T>::load(res + r * C + col);
@@ -306,17 +298,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     if (dres) Vec8<T>::store(dres + r * C + col, dz);
     Vec8<T>::store(dx + r * C + col, gi * (dz - mb - xh * mg));
   };
-  long r = (long)blockIdx.x * rlanes + rl;
-  for (; r + stride < M; r += 2 * stride) {
-    const long o0 = r * C + col, o1 = (r + stride) * C + col;
-    const f32x8 x0 = Vec8<T>::load(x + o0), x1 = Vec8<T>::load(x + o1);
-    const f32x8 d0 = Vec8<T>::load(dy + o0), d1 = Vec8<T>::load(dy + o1);
-    f32x8 y0 = zero8(), y1 = zero8();
-    if (rd_y) { y0 = Vec8<T>::load(y + o0); y1 = Vec8<T>::load(y + o1); }
-    one(r, x0, d0, y0);
-    one(r + stride, x1, d1, y1);
-  }
-  for (; r < M; r += stride) {
+  for (long r = (long)blockIdx.x * rlanes + rl; r < M; r += stride) {
     const long o0 = r * C + col;
     f32x8 y0 = zero8();
     if (rd_y) y0 = Vec8<T>::load(y + o0);
@@ -341,7 +323,7 @@ static int bn_forward_t(const T* x, const float* gamma, const float* beta, float
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)running_mean,
                        (const float*)running_var, eps, C, mean, invstd);
   }
-  const int gx = (int)min((long)cdiv(M, m.rlanes), 2048L);
+  const int gx = (int)min((long)cdiv(M, m.rlanes), 4096L);
   hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(gx, m.cgroups), dim3(256), 0, st, x, (const float*)mean,
                      (const float*)invstd, gamma, beta, res, y, M, C, m.cthreads, act);
   MMSA_CHECK_LAUNCH();
@@ -372,7 +354,7 @@ static int bn_backward_t(const T* dy, const T* x, const T* y, const float* mean,
                      beta, ws, M, C, m.cthreads, rpc, act);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, BN_FIN_COLS)), dim3(256), 0, st, (const float*)ws, chunks, C, sums,
                      dgamma, dbeta, accumulate);
-  const int gx = (int)min((long)cdiv(M, m.rlanes), 2048L);
+  const int gx = (int)min((long)cdiv(M, m.rlanes), 4096L);
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(gx, m.cgroups), dim3(256), 0, st, dy, x, y, mean, invstd, gamma, beta,
                      (const float*)sums, dx, dres, M, C, m.cthreads, act, training);
   MMSA_CHECK_LAUNCH();
