@@ -92,6 +92,11 @@ typedef struct mmsa_gemm_desc {
 
 size_t mmsa_gemm_ws_bytes(int32_t M, int32_t N, int32_t split_k);
 int mmsa_gemm(const mmsa_gemm_desc* d, int32_t impl, void* stream);
+/* n (2..4) independent weight-gradient GEMMs with the same K as ONE launch of the bf16 MFMA kernel: every descriptor must
+ * have a_kmajor = b_kmajor = 1, out_f32 = 1, no epilogue operands, no split. This is how the backward of a BERT layer
+ * issues its four dW = dY^T X products (the `.backward()` of the reference's train step, Trainer.py:79, reaches them
+ * through autograd). Returns MMSA_ERR_UNSUPPORTED (3) when the problems cannot be grouped; nothing is launched then. */
+int mmsa_gemm_group(const mmsa_gemm_desc* d, int32_t n, void* stream);
 
 /* ---- LayerNorm (nn.LayerNorm: MultimodalModel.py:122,149 eps 1e-5; BERT eps 1e-12) ------------------------- */
 int mmsa_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,

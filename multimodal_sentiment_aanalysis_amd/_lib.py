@@ -93,6 +93,7 @@ def _declare(L):
     sig = {
         "mmsa_gemm_ws_bytes": (sz, [i32, i32, i32]),
         "mmsa_gemm": (ctypes.c_int, [ctypes.POINTER(GemmDesc), i32, vp]),
+        "mmsa_gemm_group": (ctypes.c_int, [ctypes.POINTER(GemmDesc), i32, vp]),
         "mmsa_layernorm_fwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
         "mmsa_layernorm_bwd_ws_bytes": (sz, [i32]),
         "mmsa_layernorm_bwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),

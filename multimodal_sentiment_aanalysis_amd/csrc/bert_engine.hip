@@ -73,7 +73,7 @@ struct BertWs {
   float *mean0, *rstd0;
   std::vector<BertLayerWs> L;
   void *pooled, *dfeat_t, *dpool, *dprepool;
-  void *bufA, *bufB, *bufC, *bufI, *bufQ;
+  void *bufA, *bufB, *bufC, *bufD, *bufI, *bufQ;
   float *splitk, *colws, *lnws, *attnws;
   size_t splitk_bytes;
   size_t total;
@@ -111,6 +111,7 @@ static BertWs bert_ws(const mmsa_bert_cfg& c, void* base) {
   w.bufA = b.take(M * H * es);
   w.bufB = b.take(M * H * es);
   w.bufC = b.take(M * H * es);
+  w.bufD = b.take(M * H * es);
   w.bufI = b.take(M * I * es);
   w.bufQ = b.take(M * 3 * H * es);
   // split-K slabs: the largest weight gradient is [I][H]; allow up to 8 slabs of it (pick_split respects the size)
@@ -227,25 +228,30 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
     // ds2 is also dY of the FFN output Linear: its bias gradient (column sums of ds2) comes out of the same pass
     RET_IF(layernorm_bwd(c.dtype, dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, G(f.ln2w), G(f.ln2b), acc, ws.lnws, M, H, st,
                          G(f.b2)));
-    RET_IF(e.linear_wgrad(ds2, H, a.act, I, G(f.w2), M, H, I, acc));
     void* dpre = ws.bufI;
     RET_IF(e.linear_dgrad(ds2, H, W(f.w2), dpre, I, M, H, I, a.pre, I));  // * gelu'(pre)
-    RET_IF(e.bias_grad(dpre, I, G(f.b1), M, I, acc));
-    RET_IF(e.linear_wgrad(dpre, I, a.h1, H, G(f.w1), M, I, H, acc));
     void* dh1 = bC;
     RET_IF(e.linear_dgrad(dpre, I, W(f.w1), dh1, H, M, I, H, nullptr, 0, ds2, H));  // + residual branch
     void* ds1 = dOut;
     RET_IF(layernorm_bwd(c.dtype, dh1, a.s1, a.mean1, a.rstd1, P(f.ln1w), ds1, G(f.ln1w), G(f.ln1b), acc, ws.lnws, M, H, st,
                          G(f.bo)));  // + bias gradient of the attention output Linear
-    RET_IF(e.linear_wgrad(ds1, H, a.ctx, H, G(f.wo), M, H, H, acc));
-    void* dctx = bB;
+    void* dctx = ws.bufD;
     RET_IF(e.linear_dgrad(ds1, H, W(f.wo), dctx, H, M, H, H));
     void* dqkv = ws.bufQ;
     RET_IF(attention_bwd(aimpl, a.qkv, mask, dctx, dqkv, ws.attnws, B, S, c.heads, 64, st));
-    RET_IF(e.bias_grad(dqkv, 3 * H, G(f.bqkv), M, 3 * H, acc));
-    RET_IF(e.linear_wgrad(dqkv, 3 * H, xin, H, G(f.wqkv), M, 3 * H, H, acc));
     void* dx = bC;
     RET_IF(e.linear_dgrad(dqkv, 3 * H, W(f.wqkv), dx, H, M, 3 * H, H, nullptr, 0, ds1, H));  // + residual branch
+    // the layer's four weight gradients (K = B*S rows each, 18-72 tiles of 256x128) as one launch: together they fill
+    // the chip without a K split; the two bias gradients the LayerNorm backward does not produce ride along as column sums
+    {
+      const Eng::WgradJob jobs[4] = {
+          {ds2, H, a.act, I, G(f.w2), nullptr, H, I},
+          {dpre, I, a.h1, H, G(f.w1), G(f.b1), I, H},
+          {ds1, H, a.ctx, H, G(f.wo), nullptr, H, H},
+          {dqkv, 3L * H, xin, H, G(f.wqkv), G(f.bqkv), 3 * H, H},
+      };
+      RET_IF(e.wgrad_group(jobs, 4, M, acc));
+    }
     // rotate: dx becomes the next layer's dOut
     void* t = dOut; dOut = bC; bC = t;
   }

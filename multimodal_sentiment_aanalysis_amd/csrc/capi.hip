@@ -50,6 +50,17 @@ int mmsa_gemm(const mmsa_gemm_desc* d, int32_t impl, void* stream) {
   }
 }
 
+int mmsa_gemm_group(const mmsa_gemm_desc* d, int32_t n, void* stream) {
+  if (!d || n < 1 || n > 4) return MMSA_ERR_ARG;
+  GemmParams ps[4];
+  float* cs[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int g = 0; g < n; ++g) {
+    if (!d[g].A || !d[g].B || !d[g].C) return MMSA_ERR_ARG;
+    ps[g] = to_params(&d[g]);
+  }
+  return gemm_bf16_launch_group(ps, cs, n, (hipStream_t)stream);
+}
+
 int mmsa_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                        float* rstd, int32_t M, int32_t H, float eps, void* stream) {
   if (!x || !gamma || !beta || !y || M <= 0) return MMSA_ERR_ARG;

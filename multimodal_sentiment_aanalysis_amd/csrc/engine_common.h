@@ -159,6 +159,35 @@ struct Eng {
     p.ws = splitk_ws;
     return gemm(p);
   }
+  // Up to 4 weight gradients dW_g[N_g, K_g] = dy_g[M, N_g]^T x_g[M, K_g] (+ bias gradients db_g = column sums of dy_g) of
+  // one layer as ONE launch when the MFMA path can group them; otherwise one by one (+ separate column sums).
+  struct WgradJob { const void* dy; long lddy; const void* x; long ldx; float* dW; float* db; int N, K; };
+  int wgrad_group(const WgradJob* jobs, int n, int M, int accumulate) const {
+    if (dtype == MMSA_BF16 && !force_simt() && !accumulate && n >= 2 && n <= 4) {
+      GemmParams ps[4];
+      float* cs[4];
+      for (int g = 0; g < n; ++g) {
+        GemmParams p = blank();
+        p.A = jobs[g].dy; p.lda = jobs[g].lddy; p.a_kmajor = 1; p.B = jobs[g].x; p.ldb = jobs[g].ldx; p.b_kmajor = 1;
+        p.C = jobs[g].dW; p.ldc = jobs[g].K; p.M = jobs[g].N; p.N = jobs[g].K; p.K = M; p.out_f32 = 1;
+        ps[g] = p;
+        cs[g] = nullptr;  // (the kernel can fuse the column sums — G2_GROUP_COLSUM — but the extra accumulators make the
+                          //  256x128 variant spill inside its main loop; the bias gradients stay separate launches)
+      }
+      const int rc = gemm_bf16_launch_group(ps, cs, n, st);
+      if (rc != MMSA_ERR_UNSUPPORTED) {
+        if (rc) return rc;
+        for (int g = 0; g < n; ++g)
+          if (jobs[g].db) RET_IF(bias_grad(jobs[g].dy, jobs[g].lddy, jobs[g].db, M, jobs[g].N, accumulate));
+        return MMSA_OK;
+      }
+    }
+    for (int g = 0; g < n; ++g) {
+      if (jobs[g].db) RET_IF(bias_grad(jobs[g].dy, jobs[g].lddy, jobs[g].db, M, jobs[g].N, accumulate));
+      RET_IF(linear_wgrad(jobs[g].dy, jobs[g].lddy, jobs[g].x, jobs[g].ldx, jobs[g].dW, M, jobs[g].N, jobs[g].K, accumulate));
+    }
+    return MMSA_OK;
+  }
   int bias_grad(const void* dy, long lddy, float* db, int M, int N, int accumulate) const {
     return colsum(dtype, dy, lddy, db, accumulate, col_ws, M, N, st);
   }

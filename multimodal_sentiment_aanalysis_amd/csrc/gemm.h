@@ -66,6 +66,8 @@ struct GemmParams {
 int gemm_bf16_launch(const GemmParams& p, hipStream_t st);
 bool gemm2_eligible(const GemmParams& p);
 int gemm2_launch(const GemmParams& p, size_t ws_bytes_avail, hipStream_t st);
+int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st);
+int gemm_bf16_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st);  // + roofline record
 int gemm_f32_launch(const GemmParams& p, hipStream_t st);
 size_t gemm_splitk_ws_bytes(int M, int N, int split_k);
 const void* mmsa_zero_page();

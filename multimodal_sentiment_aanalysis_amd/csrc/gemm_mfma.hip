@@ -435,6 +435,24 @@ int gemm_bf16_launch(const GemmParams& pin, hipStream_t st) {
   return rc;
 }
 
+// grouped weight-gradient launch (gemm_mfma2.hip) with one roofline record for the whole group
+int gemm_bf16_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st) {
+  static const bool v1_only = [] { const char* v = getenv("MMSA_GEMM_V1"); return v && atoi(v) != 0; }();
+  static const bool no_group = [] { const char* v = getenv("MMSA_G2_NOGROUP"); return v && atoi(v) != 0; }();
+  if (v1_only || no_group || use_regstage()) return MMSA_ERR_UNSUPPORTED;
+  if (!g_prof_on || g_prof_used >= g_prof.size()) return gemm2_launch_group(probs, colsum, n, st);
+  ProfRec& r = g_prof[g_prof_used];
+  r.flop = 0;
+  for (int g = 0; g < n; ++g) r.flop += 2.0 * probs[g].M * probs[g].N * (double)probs[g].K;
+  r.M = -n; r.N = 0; r.K = probs[0].K; r.akm = 1; r.bkm = 1; r.gather = 0; r.split = 1;
+  (void)hipEventRecord(r.a, st);
+  const int rc = gemm2_launch_group(probs, colsum, n, st);
+  if (rc == MMSA_ERR_UNSUPPORTED) return rc;  // nothing was launched: the record is reused by the fallback launches
+  (void)hipEventRecord(r.b, st);
+  ++g_prof_used;
+  return rc;
+}
+
 static int gemm_bf16_launch_inner(const GemmParams& pin, hipStream_t st) {
   GemmParams p = pin;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MMSA_ERR_ARG;

@@ -20,6 +20,7 @@
 // LDS images, swizzles and fragment reads are those of gemm_tile.h (shared with the first-generation kernel).
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include <vector>
 #include "gemm.h"
@@ -32,6 +33,9 @@
 #define G2_B_BYTES 16384
 #define G2_STAGE (G2_A_BYTES + G2_B_BYTES)
 #define G2_LDS (3 * G2_STAGE)
+#ifndef G2_GROUP_COLSUM
+#define G2_GROUP_COLSUM 0
+#endif
 
 struct G2Sched {
   int ntm, ntn, ntiles;  // tile grid
@@ -43,6 +47,15 @@ struct G2Sched {
   unsigned c_bytes;      // byte extent of the output view (C, or the split-K slabs)
   int rb, cb;            // 2-D blocking of the tile order (rb x cb tiles = one XCD's round), 0 = row-major
   FastDiv fd_cb, fd_sbc;  // divisors: cb, super-blocks per row of super-blocks
+  // grouped launch (weight gradients of one BERT layer): up to 4 independent TN problems with the same K share one
+  // launch, so their 18-72 tiles each add up to ~216 work items without any K split (no slabs, no reducer)
+  int ngroups;
+  struct Group {
+    const void* A; const void* B; void* C; float* colsum;  // colsum: optional sum_k A[k][m] (the bias gradient)
+    int M, N; long lda, ldb, ldc;
+    int tile_begin, ntn;
+    unsigned a_bytes, b_bytes, c_bytes;
+  } grp[4];
   int dbg;               // timing-only ablations (MMSA_G2_DBG bitmask; results are wrong): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no epilogue
 };
 
@@ -119,9 +132,24 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   if (lb >= s.items) return;
 
   // ---- item decode (all scalar)
-  struct Item { int m0, n0, kb, nk, sp; };
+  constexpr bool GROUPS = A_KM && B_KM && GATHER == 0;  // only the TN instantiations carry the group code
+  constexpr bool GCOLSUM = GROUPS && G2_GROUP_COLSUM;   // ... and (optionally) the fused column sums
+  struct Item { int m0, n0, kb, nk, sp, grp, tn; };
   auto decode = [&](int item) __attribute__((always_inline)) -> Item {
     Item it;
+    it.grp = 0;
+    if constexpr (GROUPS) {
+      if (s.ngroups > 0) {
+        int g = 0;
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          if (q < s.ngroups && item >= s.grp[q].tile_begin) g = q;
+        const int tile = item - s.grp[g].tile_begin;
+        const int tm = tile / s.grp[g].ntn, tn = tile - tm * s.grp[g].ntn;
+        it.m0 = tm * BM; it.n0 = tn * BN; it.sp = 0; it.kb = 0; it.nk = s.nsteps; it.grp = g; it.tn = tn;
+        return it;
+      }
+    }
     const int sp = (int)fd_div((uint32_t)item, s.fd_ntiles);
     const int tile = item - sp * s.ntiles;
     int tm, tn;
@@ -136,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       tm = (int)fd_div((uint32_t)tile, s.fd_ntn);
       tn = tile - tm * s.ntn;
     }
-    it.m0 = tm * BM; it.n0 = tn * BN; it.sp = sp;
+    it.m0 = tm * BM; it.n0 = tn * BN; it.sp = sp; it.tn = tn;
     it.kb = sp * s.per;
     it.nk = min(s.per, s.nsteps - it.kb);
     return it;
@@ -151,40 +179,37 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   // source offset of a row changes with the tap, so it is recomputed per K step from the row's decomposed pixel;
   // GATHER 2 = the k-major B rows (k) are output pixels and the columns are (tap, channel): the pixel of a lane's k-row
   // is decomposed per K step. A K step never straddles a tap (cper % 64 == 0 is checked by the launcher).
-  int relA[NPA], rcA[NPA], relB[NLB], rcB[NLB];  // rc = row (k-contiguous) or first column (k-major) inside the tile
-  int krowB[NLB];                            // GATHER 2: k-row of the lane's B chunk inside a K step
+  // Per-lane staging map, recomputed from the lane id whenever the loader enters an item (a handful of VALU per
+  // item) instead of living in ~18 VGPRs through the main loop (the 256 x 128 variants were spilling):
+  //   rc  = row (k-contiguous operand) or first column (k-major) of the lane's 16-byte chunk inside the tile
+  //   rel = its byte offset inside the tile for the current leading dimension (tile origin and K advance are scalar)
   const int kc8 = ((lane & 7) ^ (lane >> 3)) * 8;
-  {
-    const int kc = (lane & 7) ^ (lane >> 3);
+  // the loader's view of the problem (changes with the group of the item being loaded)
+  int lM = p.M, lN = p.N;
+  long llda = p.lda, lldb = p.ldb;
+  auto krow_km = [&](int pi) __attribute__((always_inline)) -> int { return 4 * (pi & 15) + (lane >> 4); };
+  auto col_km = [&](int krow) __attribute__((always_inline)) -> int {
     const int pc = lane & 15;
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-      const int pi = wave * NPA + i;
-      if constexpr (!A_KM) {
-        rcA[i] = pi * 8 + (lane >> 3);
-        relA[i] = (int)(((long)rcA[i] * p.lda + kc * 8) * 2);
-      } else {  // two [64][128] halves; piece = 4 k-rows of one half
-        const int half = pi >> 4, krow = 4 * (pi & 15) + (lane >> 4);
-        const int cc = ((((pc >> 1) ^ kmajor_swz(krow)) << 1) | (pc & 1));
-        rcA[i] = half * 128 + cc * 8;
-        relA[i] = (int)(((long)krow * p.lda + rcA[i]) * 2);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-      const int pi = wave * NLB + i;
-      if constexpr (!B_KM) {
-        rcB[i] = pi * 8 + (lane >> 3);
-        relB[i] = (int)(((long)rcB[i] * p.ldb + kc * 8) * 2);
-      } else {
-        const int krow = 4 * pi + (lane >> 4);
-        const int cc = ((((pc >> 1) ^ kmajor_swz(krow)) << 1) | (pc & 1));
-        rcB[i] = cc * 8;
-        relB[i] = (int)(((long)krow * p.ldb + rcB[i]) * 2);
-        krowB[i] = krow;
-      }
-    }
-  }
+    return ((((pc >> 1) ^ kmajor_swz(krow)) << 1) | (pc & 1)) * 8;
+  };
+  auto rcA_of = [&](int i) __attribute__((always_inline)) -> int {
+    const int pi = wave * NPA + i;
+    if constexpr (!A_KM) return pi * 8 + (lane >> 3);
+    else return (pi >> 4) * 128 + col_km(krow_km(pi));  // two [64][128] halves; piece = 4 k-rows of one half
+  };
+  auto relA_of = [&](int i) __attribute__((always_inline)) -> int {
+    if constexpr (!A_KM) return (int)(((long)rcA_of(i) * llda + kc8) * 2);
+    else return (int)(((long)krow_km(wave * NPA + i) * llda + rcA_of(i)) * 2);
+  };
+  auto krowB_of = [&](int i) __attribute__((always_inline)) -> int { return 4 * (wave * NLB + i) + (lane >> 4); };
+  auto rcB_of = [&](int i) __attribute__((always_inline)) -> int {
+    if constexpr (!B_KM) return (wave * NLB + i) * 8 + (lane >> 3);
+    else return col_km(krowB_of(i));
+  };
+  auto relB_of = [&](int i) __attribute__((always_inline)) -> int {
+    if constexpr (!B_KM) return (int)(((long)rcB_of(i) * lldb + kc8) * 2);
+    else return (int)(((long)krowB_of(i) * lldb + rcB_of(i)) * 2);
+  };
   __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsrcC =
@@ -196,23 +221,33 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   int voffA[NPA], voffB[NLB];
   RowPix a_pix[NPA];                       // GATHER 1: decomposed pixel of the lane's 4 A rows of the current tile
   int b_ky[NLB], b_kx[NLB], b_coff[NLB];  // GATHER 2: tap and channel offset of the lane's B column chunks
+  int l_grp = -1;
   auto loader_setup = [&]() __attribute__((always_inline)) {
+    if constexpr (GROUPS) {
+      if (s.ngroups > 0 && L.grp != l_grp) {  // the loader enters another problem of the group
+        l_grp = L.grp;
+        lM = s.grp[l_grp].M; lN = s.grp[l_grp].N; llda = s.grp[l_grp].lda; lldb = s.grp[l_grp].ldb;
+        rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)s.grp[l_grp].A, 0, s.grp[l_grp].a_bytes, 0x00020000);
+        rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)s.grp[l_grp].B, 0, s.grp[l_grp].b_bytes, 0x00020000);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
-      if constexpr (GATHER == 1) a_pix[i] = decompose_pixel(p.g, L.m0 + rcA[i], p.M);
-      else voffA[i] = (L.m0 + rcA[i] < p.M) ? relA[i] : OOB;
+      if constexpr (GATHER == 1) a_pix[i] = decompose_pixel(p.g, L.m0 + rcA_of(i), lM);
+      else voffA[i] = (L.m0 + rcA_of(i) < lM) ? relA_of(i) : OOB;
     }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
-      const bool ok = rcB[i] < BN && L.n0 + rcB[i] < p.N;
+      const int rcb = rcB_of(i);
+      const bool ok = rcb < BN && L.n0 + rcb < lN;
       if constexpr (GATHER == 2) {
-        const int col = L.n0 + rcB[i];
+        const int col = L.n0 + rcb;
         const uint32_t tap = fd_div((uint32_t)col, p.g.fd_cper);
         b_coff[i] = ok ? col - (int)tap * p.g.cper : -1;
         b_ky[i] = (int)fd_div(tap, p.g.fd_kw);
         b_kx[i] = (int)tap - b_ky[i] * p.g.KW;
       } else {
-        voffB[i] = ok ? relB[i] : OOB;
+        voffB[i] = ok ? relB_of(i) : OOB;
       }
     }
   };
@@ -232,21 +267,21 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       }
       d_soffA = c0 * 2;
       if constexpr (B_KM)  // weight [cout][tap][cin] read as k-major rows k = (tap, cout): row (k % cper), tap offset
-        d_soffB = (int)(((long)c0 * p.ldb + (long)tap * p.b_tap_stride + L.n0) * 2);
+        d_soffB = (int)(((long)c0 * lldb + (long)tap * p.b_tap_stride + L.n0) * 2);
       else
-        d_soffB = (int)(((long)L.n0 * p.ldb + k0) * 2);
+        d_soffB = (int)(((long)L.n0 * lldb + k0) * 2);
     } else if constexpr (GATHER == 2) {
-      d_soffA = (int)(((long)k0 * p.lda + L.m0) * 2);
+      d_soffA = (int)(((long)k0 * llda + L.m0) * 2);
 #pragma unroll
       for (int i = 0; i < NLB; ++i) {
-        const RowPix px = decompose_pixel(p.g, k0 + krowB[i], p.K);
+        const RowPix px = decompose_pixel(p.g, k0 + krowB_of(i), p.K);
         const long src = tap_src(p.g, px, b_ky[i], b_kx[i]);
         voffB[i] = (src >= 0 && b_coff[i] >= 0) ? (int)((src + b_coff[i]) * 2) : OOB;
       }
       d_soffB = 0;
     } else {
-      d_soffA = A_KM ? (int)(((long)k0 * p.lda + L.m0) * 2) : (int)(((long)L.m0 * p.lda + k0) * 2);
-      d_soffB = B_KM ? (int)(((long)k0 * p.ldb + L.n0) * 2) : (int)(((long)L.n0 * p.ldb + k0) * 2);
+      d_soffA = A_KM ? (int)(((long)k0 * llda + L.m0) * 2) : (int)(((long)L.m0 * llda + k0) * 2);
+      d_soffB = B_KM ? (int)(((long)k0 * lldb + L.n0) * 2) : (int)(((long)L.n0 * lldb + k0) * 2);
     }
   };
   auto dma_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
@@ -283,6 +318,24 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   // ---- compute cursor
   int c_item = lb, c_kt = 0;
   Item C = decode(c_item);
+  // the epilogue's view of the problem (the compute cursor's group) and the optional column-sum accumulators
+  int eM = p.M, eN = p.N;
+  long eldc = p.ldc;
+  float* e_colsum = nullptr;
+  f32x4 accb[4];  // GROUPS: sum_k A[k][m] for the wave's 64 rows m (every lane row n holds the same value)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto compute_setup = [&]() __attribute__((always_inline)) {
+    if constexpr (GROUPS) {
+      if (s.ngroups > 0) {
+        const int g = C.grp;
+        eM = s.grp[g].M; eN = s.grp[g].N; eldc = s.grp[g].ldc;
+        e_colsum = C.tn == 0 ? s.grp[g].colsum : nullptr;
+        rsrcC = __builtin_amdgcn_make_buffer_rsrc(s.grp[g].C, 0, s.grp[g].c_bytes, 0x00020000);
+      }
+    }
+  };
+  compute_setup();
   f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -293,14 +346,14 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   auto epilogue = [&]() __attribute__((always_inline)) -> int {  // returns the store units it issued (0: it drained the queue)
     const int mb = C.m0 + wm * 64 + r16, nb = C.n0 + wn * (NJ * 16) + 4 * g4;
     if (s.split_k > 1) {  // raw fp32 partials -> slab sp
-      const long slab = (long)C.sp * p.M * p.N;
+      const long slab = (long)C.sp * eM * eN;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = mb + i * 16;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int n = nb + j * 16;
-          const int vo = (m < p.M && n < p.N) ? (int)((slab + (long)m * p.N + n) * 4) : OOB;
+          const int vo = (m < eM && n < eN) ? (int)((slab + (long)m * eN + n) * 4) : OOB;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, acc[i][j]), rsrcC, vo, 0, 0);
         }
       }
@@ -314,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             const int n = nb + j * 16;
-            const int vo = (m < p.M && n < p.N) ? (int)(((long)m * p.ldc + n) * 4) : OOB;
+            const int vo = (m < eM && n < eN) ? (int)(((long)m * eldc + n) * 4) : OOB;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, acc[i][j]), rsrcC, vo, 0, 0);
           }
         }
@@ -337,9 +390,22 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
             const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)xi[0], (unsigned)yi[0], false, false);
             const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)xi[1], (unsigned)yi[1], false, false);
             const i32x4 d = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
-            const int vo = (m < p.M && n < p.N) ? (int)(((long)m * p.ldc + n) * 2) : OOB;
+            const int vo = (m < eM && n < eN) ? (int)(((long)m * eldc + n) * 2) : OOB;
             __builtin_amdgcn_raw_buffer_store_b128(d, rsrcC, vo, 0, 0);
           }
+        }
+      }
+      if constexpr (GCOLSUM) {
+        if (e_colsum) {  // bias gradient of this row panel: lanes of lane-row 0 of the wn = 0 waves hold it
+          __amdgpu_buffer_rsrc_t rcs = __builtin_amdgcn_make_buffer_rsrc((void*)e_colsum, 0, eM * 4, 0x00020000);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = C.m0 + wm * 64 + i * 16 + r16;
+            const int vo = (wn == 0 && g4 == 0 && m < eM) ? m * 4 : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, accb[i][0]), rcs, vo, 0, 0);
+          }
+          wait_vm<0>();  // not a counted epilogue
+          return 0;
         }
       }
       return p.out_f32 ? 2 : 1;
@@ -519,12 +585,24 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       if constexpr (NJ > 3) fb[3] = lds_rd_tr<kk * 8192>(offB[3] + so);
     }
   };
+  // column sums of A on the matrix pipe: D[n][m] = sum_k 1 * A[m][k] with an all-ones operand in place of the B fragment
+  auto mma_colsum = [&](const bf16x8(&fa)[4]) __attribute__((always_inline)) {
+    if constexpr (GCOLSUM) {
+      if (e_colsum) {
+        const bf16 one = (bf16)1.0f;
+        const bf16x8 ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], accb[i], 0, 0, 0);
+      }
+    }
+  };
   auto mma_half = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[NJ]) __attribute__((always_inline)) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    mma_colsum(fa);
     __builtin_amdgcn_s_setprio(0);
   };
   // the same 4 x NJ MFMAs with half of the LDS-DMA instructions of a K step spread between them. The refill of the
@@ -563,6 +641,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       one(std::integral_constant<int, 12>{}); one(std::integral_constant<int, 13>{});
       one(std::integral_constant<int, 14>{}); one(std::integral_constant<int, 15>{});
     }
+    mma_colsum(fa);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (PART == 1) dma_advance();
@@ -619,9 +698,16 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (GCOLSUM) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       c_kt = 0;
       c_item += G;
-      if (c_item < s.items) C = decode(c_item);
+      if (c_item < s.items) {
+        C = decode(c_item);
+        compute_setup();
+      }
     }
     eu1 = e;
     st = nst;
@@ -822,6 +908,7 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   s.fast = (!p.bias && !p.C2 && p.act == MMSA_ACT_NONE && !p.mul && !p.add && !(p.out_f32 && p.accumulate)) ? 1 : 0;
   p.split_k = s.split_k;
   s.dbg = 0;
+  s.ngroups = 0;
   if (const char* d = getenv("MMSA_G2_DBG")) s.dbg = atoi(d);
   s.c_bytes = s.split_k > 1 ? (unsigned)slab_bytes : (unsigned)(((long)(p.M - 1) * p.ldc + p.N) * (p.out_f32 ? 4 : 2));
   {
@@ -849,4 +936,66 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
     MMSA_CHECK_LAUNCH();
   }
   return MMSA_OK;
+}
+
+// Grouped launch: n (2..4) independent weight-gradient problems C_g[M_g, N_g] = A_g^T B_g with the same K, both operands
+// k-major, fp32 output (overwrite), no K split: one persistent launch walks the tiles of all problems. colsum[g]
+// (optional) receives sum_k A_g[k][m] = the bias gradient of that Linear. Returns MMSA_ERR_UNSUPPORTED when the
+// problems do not fit (the caller then launches them one by one).
+int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st) {
+  if (n < 1 || n > 4) return MMSA_ERR_UNSUPPORTED;
+  const int K = probs[0].K;
+  for (int g = 0; g < n; ++g) {
+    const GemmParams& q = probs[g];
+    if (!(q.a_kmajor && q.b_kmajor) || q.gather || q.K != K || !q.out_f32 || q.accumulate || q.bias || q.C2 || q.mul ||
+        q.add || q.act != MMSA_ACT_NONE || !gemm2_eligible(q))
+      return MMSA_ERR_UNSUPPORTED;
+  }
+  const int cus = g2_num_cus();
+  // one tile shape for the whole group: the widest 256-row tile whose total tile count fills the chip best
+  G2Plan plan{4, 4, 1};
+  {
+    double best = 1e300;
+    for (int nj = 4; nj >= 2; --nj) {
+      long tiles = 0;
+      for (int g = 0; g < n; ++g) tiles += (long)cdiv(probs[g].M, 256) * cdiv(probs[g].N, nj * 32);
+      const long rounds = (tiles + cus - 1) / cus;
+      const double cost = rounds * ((K / G2_BK) * (1.0 + 0.06 * nj) + 0.3 + 0.2 * nj);
+      if (cost < best - 1e-9) { best = cost; plan.nj = nj; }
+    }
+  }
+  G2Sched s;
+  memset(&s, 0, sizeof(s));
+  const int bn = g2_bn(plan);
+  s.ngroups = n;
+  int tiles = 0;
+  for (int g = 0; g < n; ++g) {
+    const GemmParams& q = probs[g];
+    G2Sched::Group& gr = s.grp[g];
+    gr.A = q.A; gr.B = q.B; gr.C = q.C; gr.colsum = colsum ? colsum[g] : nullptr;
+    gr.M = q.M; gr.N = q.N; gr.lda = q.lda; gr.ldb = q.ldb; gr.ldc = q.ldc;
+    gr.tile_begin = tiles;
+    gr.ntn = cdiv(q.N, bn);
+    tiles += cdiv(q.M, 256) * gr.ntn;
+    long ea, eb;
+    g2_extents(q, &ea, &eb);
+    gr.a_bytes = (unsigned)ea; gr.b_bytes = (unsigned)eb;
+    gr.c_bytes = (unsigned)(((long)(q.M - 1) * q.ldc + q.N) * 4);
+  }
+  s.ntm = 1; s.ntn = 1; s.ntiles = tiles;
+  s.nsteps = K / G2_BK;
+  s.split_k = 1; s.per = s.nsteps; s.items = tiles;
+  s.fd_ntiles = make_fastdiv((uint32_t)tiles);
+  s.fd_ntn = make_fastdiv(1);
+  s.fd_cb = make_fastdiv(1); s.fd_sbc = make_fastdiv(1);
+  s.fast = 1;
+  s.c_bytes = s.grp[0].c_bytes;
+  if (const char* d = getenv("MMSA_G2_DBG")) s.dbg = atoi(d);
+  GemmParams p = probs[0];
+  p.split_k = 1;
+  p.a_bytes = s.grp[0].a_bytes; p.b_bytes = s.grp[0].b_bytes;
+  const int grid = tiles < cus ? tiles : cus;
+  if (plan.nj == 4) return g2_launch_t<4, 4, true, true, 0>(p, s, grid, st);
+  if (plan.nj == 3) return g2_launch_t<4, 3, true, true, 0>(p, s, grid, st);
+  return g2_launch_t<4, 2, true, true, 0>(p, s, grid, st);
 }

@@ -66,6 +66,21 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, gather=0, geom
     return C
 
 
+def gemm_group(jobs):
+    """jobs: list of (A[K,M] k-major, B[K,N] k-major, C[M,N] fp32) -> one grouped weight-gradient launch (mmsa_gemm_group).
+    Returns the status code (3 = the library declined to group them)."""
+    L = _lib.load()
+    arr = (GemmDesc * len(jobs))()
+    for d, (A, B, C) in zip(arr, jobs):
+        Kd, M = A.shape
+        N = B.shape[1]
+        d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+        d.M, d.N, d.K = M, N, Kd
+        d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), C.stride(0)
+        d.a_kmajor, d.b_kmajor, d.out_f32, d.split_k = 1, 1, 1, 1
+    return L.mmsa_gemm_group(arr, len(jobs), stream_ptr())
+
+
 def layernorm_fwd(x, gamma, beta, eps):
     L = _lib.load()
     M, H = x.shape

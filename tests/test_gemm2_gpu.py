@@ -177,3 +177,19 @@ def test_g2_conv(dev, cfg, nj):
         K.gemm(dy, x, dw, Cout, Kd, B * OH * OW, Cout, Cin, Kd, a_kmajor=1, b_kmajor=1, gather=2, geom=g, out_f32=1,
                split_k=16, impl=GEMM_BF16_MFMA)
         close(dw.view(Cout, k, k, Cin), wr.grad.permute(0, 2, 3, 1), "conv wgrad", tol=2e-3)
+
+
+def test_g2_group(dev):
+    """The four weight gradients of a BERT-base layer (K = 8192 rows) as one grouped launch, and a ragged small group."""
+    for Kd, shapes in [(8192, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]), (640, [(136, 264), (520, 72), (64, 64)])]:
+        jobs, refs = [], []
+        for i, (M, N) in enumerate(shapes):
+            A = rnd((Kd, M), dev, 10 + i, 0.5)
+            B = rnd((Kd, N), dev, 20 + i, 0.5)
+            C = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+            jobs.append((A, B, C))
+            refs.append(A.double().T @ B.double())
+        rc = K.gemm_group(jobs)
+        assert rc == 0, rc
+        for (A, B, C), ref in zip(jobs, refs):
+            close(C.double(), ref, f"group K={Kd} {tuple(C.shape)}", tol=2e-5)
