@@ -231,6 +231,14 @@ int mmsa_stem_im2col(int32_t dtype, const float* img, void* col, int32_t B, int3
  * its split-K reduction) is bracketed by HIP events on its launch stream. mmsa_prof_end must be called after the
  * stream has been synchronized; it returns the summed device time, the algorithmic flop (2*M*N*K) and the count. */
 int mmsa_prof_begin(int32_t max_records);
+/* Sampling: only launches whose running index (reset by this call) satisfies index % stride == phase are bracketed.
+ * An event pair drains the queue around its kernel (+5..15 us per launch when every launch is bracketed), so bench.py
+ * brackets every 5th launch in each of 5 steps, rotating the phase: each launch is measured once, undisturbed. */
+int mmsa_prof_sample(int32_t stride, int32_t phase);
+/* mode 0 (default): HIP events around each sampled launch. mode 1: no events; the MFMA GEMM kernels (and the split-K
+ * reducer) stamp {first workgroup start, last workgroup end} with s_memrealtime (100 MHz) into a device record —
+ * the kernel's own duration, as rocprofv3 --kernel-trace reports it. Set before mmsa_prof_begin. */
+int mmsa_prof_mode(int32_t mode);
 int mmsa_prof_end(double* total_ms, double* total_flop, int64_t* launches);
 
 #ifdef __cplusplus

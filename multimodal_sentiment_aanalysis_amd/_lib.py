@@ -130,6 +130,8 @@ def _declare(L):
         "mmsa_adamw_step": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp]),
         "mmsa_cast_f32": (ctypes.c_int, [i32, vp, vp, i64, vp]),
         "mmsa_prof_begin": (ctypes.c_int, [i32]),
+        "mmsa_prof_sample": (ctypes.c_int, [i32, i32]),
+        "mmsa_prof_mode": (ctypes.c_int, [i32]),
         "mmsa_prof_end": (ctypes.c_int, [P(ctypes.c_double), P(ctypes.c_double), i64p]),
         "mmsa_bn_ws_bytes": (sz, [i32]),
         "mmsa_bn_fwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, i32, vp]),

@@ -4,6 +4,8 @@
 #include "ops.h"
 
 int gemm_prof_begin(int max_records);
+int gemm_prof_sample(int stride, int phase);
+int gemm_prof_mode(int mode);
 int gemm_prof_end(double* total_ms, double* total_flop, long* launches);
 
 static GemmParams to_params(const mmsa_gemm_desc* d) {
@@ -26,7 +28,7 @@ static GemmParams to_params(const mmsa_gemm_desc* d) {
   p.mul = d->mul; p.ldmul = d->ldmul; p.add = d->add; p.ldadd = d->ldadd;
   p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.split_k = d->split_k; p.ws = d->ws; p.ws_bytes = 0;
   p.zero_page = nullptr;
-  p.a_bytes = p.b_bytes = 0; p.use_srd = 0;
+  p.a_bytes = p.b_bytes = 0; p.use_srd = 0; p.stamp = nullptr;
   return p;
 }
 
@@ -109,6 +111,8 @@ int mmsa_cast_f32(int32_t dtype, const float* src, void* dst, int64_t n, void* s
 }
 
 int mmsa_prof_begin(int32_t max_records) { return gemm_prof_begin(max_records); }
+int mmsa_prof_sample(int32_t stride, int32_t phase) { return gemm_prof_sample(stride, phase); }
+int mmsa_prof_mode(int32_t mode) { return gemm_prof_mode(mode); }
 int mmsa_prof_end(double* total_ms, double* total_flop, int64_t* launches) {
   if (!total_ms || !total_flop || !launches) return MMSA_ERR_ARG;
   long n = 0;

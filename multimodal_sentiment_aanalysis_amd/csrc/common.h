@@ -124,4 +124,14 @@ __device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) {
   return (uint32_t)(((uint64_t)n * (uint64_t)f.magic) >> (31 + f.shift));
 }
 
+// in-kernel timing record: stamp[0] = min start, stamp[1] = max end (s_memrealtime ticks)
+__device__ __forceinline__ void stamp_begin(unsigned long long* stamp) {
+  if (stamp && threadIdx.x == 0)
+    __hip_atomic_fetch_min(&stamp[0], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stamp_end(unsigned long long* stamp) {
+  if (stamp && threadIdx.x == 0)
+    __hip_atomic_fetch_max(&stamp[1], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -61,6 +61,9 @@ struct GemmParams {
   // filled by the MFMA launcher: byte extents of the A / B views for the buffer-descriptor staging path
   unsigned a_bytes, b_bytes;
   int use_srd;
+  // optional in-kernel timing record {min start, max end} in s_memrealtime ticks (100 MHz), filled by the MFMA kernels
+  // and the split-K reducer when non-null (bench.py roofline: HIP event pairs add ~12 us of queue drain per launch)
+  unsigned long long* stamp;
 };
 
 int gemm_bf16_launch(const GemmParams& p, hipStream_t st);

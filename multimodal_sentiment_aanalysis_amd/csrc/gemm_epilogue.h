@@ -93,6 +93,7 @@ __device__ __forceinline__ void gemm_epilogue1(const GemmParams& p, int m, int n
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p, int L) {
   __shared__ f32x4 red[256];
+  stamp_begin(p.stamp);
   const long total4 = (long)p.M * p.N / 4;
   const int opb = 256 / L;
   const int l = threadIdx.x / opb, o = threadIdx.x - l * opb;
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p, i
       gemm_epilogue4<T>(p, m, n, v);
     }
   }
+  stamp_end(p.stamp);
 }
 
 template <typename T>

@@ -377,9 +377,30 @@ static int launch_variant(const GemmParams& p, hipStream_t st) {
 
 // ---- optional live timing of the MFMA GEMM launches (bench.py roofline): HIP events on the launch stream ----------
 struct ProfRec { hipEvent_t a, b; double flop; int M, N, K, akm, bkm, gather, split; };
+static unsigned long long* g_stamp_dev = nullptr;  // [record][2]: in-kernel {min start, max end} ticks
+static size_t g_stamp_cap = 0;
+static int g_prof_mode = 0;  // 0: HIP events around each launch; 1: in-kernel clock stamps (no events)
 static std::vector<ProfRec> g_prof;
 static size_t g_prof_used = 0;
 static bool g_prof_on = false;
+static int g_prof_stride = 1, g_prof_phase = 0;
+static long g_prof_index = 0;  // running launch index since the last gemm_prof_sample()
+
+int gemm_prof_mode(int mode) {
+  if (mode != 0 && mode != 1) return MMSA_ERR_ARG;
+  g_prof_mode = mode;
+  return MMSA_OK;
+}
+int gemm_prof_sample(int stride, int phase) {
+  if (stride < 1 || phase < 0 || phase >= stride) return MMSA_ERR_ARG;
+  g_prof_stride = stride; g_prof_phase = phase; g_prof_index = 0;
+  return MMSA_OK;
+}
+static bool prof_take() {  // is this launch one of the sampled ones?
+  const bool take = (g_prof_index % g_prof_stride) == g_prof_phase;
+  ++g_prof_index;
+  return take;
+}
 
 int gemm_prof_begin(int max_records) {
   if (max_records < 0) return MMSA_ERR_ARG;
@@ -391,16 +412,43 @@ int gemm_prof_begin(int max_records) {
   }
   g_prof_used = 0;
   g_prof_on = true;
+  g_prof_stride = 1; g_prof_phase = 0; g_prof_index = 0;
+  if (g_stamp_cap < (size_t)max_records) {
+    if (g_stamp_dev) (void)hipFree(g_stamp_dev);
+    g_stamp_dev = nullptr;
+    if (hipMalloc((void**)&g_stamp_dev, (size_t)max_records * 2 * sizeof(unsigned long long)) != hipSuccess) return MMSA_ERR_LAUNCH;
+    g_stamp_cap = (size_t)max_records;
+  }
+  {
+    std::vector<unsigned long long> init((size_t)max_records * 2);
+    for (int i = 0; i < max_records; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+    if (max_records > 0 &&
+        hipMemcpy(g_stamp_dev, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) != hipSuccess)
+      return MMSA_ERR_LAUNCH;
+  }
   return MMSA_OK;
 }
 // caller must have synchronized the stream(s); returns summed kernel time, algorithmic flop and launch count
 int gemm_prof_end(double* total_ms, double* total_flop, long* launches) {
   g_prof_on = false;
+  std::vector<double> dur(g_prof_used, 0.0);  // ms per record
+  if (g_prof_mode == 1) {
+    std::vector<unsigned long long> st(g_prof_used * 2);
+    if (g_prof_used &&
+        hipMemcpy(st.data(), g_stamp_dev, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+      return MMSA_ERR_LAUNCH;
+    for (size_t i = 0; i < g_prof_used; ++i)  // s_memrealtime ticks at 100 MHz
+      dur[i] = st[2 * i + 1] > st[2 * i] ? (double)(st[2 * i + 1] - st[2 * i]) * 1e-5 : 0.0;
+  } else {
+    for (size_t i = 0; i < g_prof_used; ++i) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) return MMSA_ERR_LAUNCH;
+      dur[i] = t;
+    }
+  }
   double ms = 0, fl = 0;
   for (size_t i = 0; i < g_prof_used; ++i) {
-    float t = 0;
-    if (hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) return MMSA_ERR_LAUNCH;
-    ms += t;
+    ms += dur[i];
     fl += g_prof[i].flop;
   }
   *total_ms = ms; *total_flop = fl; *launches = (long)g_prof_used;
@@ -408,11 +456,9 @@ int gemm_prof_end(double* total_ms, double* total_flop, long* launches) {
     if (FILE* f = fopen(path, "w")) {
       fprintf(f, "M,N,K,a_kmajor,b_kmajor,gather,split_k,us,tflops\n");
       for (size_t i = 0; i < g_prof_used; ++i) {
-        float t = 0;
-        (void)hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
         const ProfRec& r = g_prof[i];
-        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.1f\n", r.M, r.N, r.K, r.akm, r.bkm, r.gather, r.split, t * 1e3,
-                t > 0 ? r.flop / (t * 1e-3) / 1e12 : 0.0);
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.1f\n", r.M, r.N, r.K, r.akm, r.bkm, r.gather, r.split, dur[i] * 1e3,
+                dur[i] > 0 ? r.flop / (dur[i] * 1e-3) / 1e12 : 0.0);
       }
       fclose(f);
     }
@@ -424,10 +470,16 @@ int gemm_prof_end(double* total_ms, double* total_flop, long* launches) {
 static int gemm_bf16_launch_inner(const GemmParams& pin, hipStream_t st);
 
 int gemm_bf16_launch(const GemmParams& pin, hipStream_t st) {
-  if (!g_prof_on || g_prof_used >= g_prof.size()) return gemm_bf16_launch_inner(pin, st);
+  if (!g_prof_on || g_prof_used >= g_prof.size() || !prof_take()) return gemm_bf16_launch_inner(pin, st);
   ProfRec& r = g_prof[g_prof_used];
   r.flop = 2.0 * pin.M * pin.N * (double)pin.K;
   r.M = pin.M; r.N = pin.N; r.K = pin.K; r.akm = pin.a_kmajor; r.bkm = pin.b_kmajor; r.gather = pin.gather; r.split = pin.split_k;
+  if (g_prof_mode == 1) {  // in-kernel clock stamps: nothing is put into the queue around the launch
+    GemmParams p = pin;
+    p.stamp = g_stamp_dev + 2 * g_prof_used;
+    ++g_prof_used;
+    return gemm_bf16_launch_inner(p, st);
+  }
   (void)hipEventRecord(r.a, st);
   const int rc = gemm_bf16_launch_inner(pin, st);
   (void)hipEventRecord(r.b, st);
@@ -440,11 +492,19 @@ int gemm_bf16_launch_group(const GemmParams* probs, float* const* colsum, int n,
   static const bool v1_only = [] { const char* v = getenv("MMSA_GEMM_V1"); return v && atoi(v) != 0; }();
   static const bool no_group = [] { const char* v = getenv("MMSA_G2_NOGROUP"); return v && atoi(v) != 0; }();
   if (v1_only || no_group || use_regstage()) return MMSA_ERR_UNSUPPORTED;
-  if (!g_prof_on || g_prof_used >= g_prof.size()) return gemm2_launch_group(probs, colsum, n, st);
+  if (!g_prof_on || g_prof_used >= g_prof.size() || !prof_take()) return gemm2_launch_group(probs, colsum, n, st);
   ProfRec& r = g_prof[g_prof_used];
   r.flop = 0;
   for (int g = 0; g < n; ++g) r.flop += 2.0 * probs[g].M * probs[g].N * (double)probs[g].K;
   r.M = -n; r.N = 0; r.K = probs[0].K; r.akm = 1; r.bkm = 1; r.gather = 0; r.split = 1;
+  if (g_prof_mode == 1) {
+    GemmParams ps[4];
+    for (int g = 0; g < n; ++g) ps[g] = probs[g];
+    ps[0].stamp = g_stamp_dev + 2 * g_prof_used;
+    const int rc = gemm2_launch_group(ps, colsum, n, st);
+    if (rc != MMSA_ERR_UNSUPPORTED) ++g_prof_used;
+    return rc;
+  }
   (void)hipEventRecord(r.a, st);
   const int rc = gemm2_launch_group(probs, colsum, n, st);
   if (rc == MMSA_ERR_UNSUPPORTED) return rc;  // nothing was launched: the record is reused by the fallback launches

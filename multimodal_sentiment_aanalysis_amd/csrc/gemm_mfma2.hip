@@ -56,6 +56,7 @@ struct G2Sched {
     int tile_begin, ntn;
     unsigned a_bytes, b_bytes, c_bytes;
   } grp[4];
+  unsigned long long* stamp;  // in-kernel timing record or null
   int dbg;               // timing-only ablations (MMSA_G2_DBG bitmask; results are wrong): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no epilogue
 };
 
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
   if (lb >= s.items) return;
+  stamp_begin(s.stamp);
 
   // ---- item decode (all scalar)
   constexpr bool GROUPS = A_KM && B_KM && GATHER == 0;  // only the TN instantiations carry the group code
@@ -712,6 +714,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     eu1 = e;
     st = nst;
   }
+  stamp_end(s.stamp);
 #endif
 }
 
@@ -909,6 +912,7 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   p.split_k = s.split_k;
   s.dbg = 0;
   s.ngroups = 0;
+  s.stamp = p.stamp;
   if (const char* d = getenv("MMSA_G2_DBG")) s.dbg = atoi(d);
   s.c_bytes = s.split_k > 1 ? (unsigned)slab_bytes : (unsigned)(((long)(p.M - 1) * p.ldc + p.N) * (p.out_f32 ? 4 : 2));
   {
@@ -989,6 +993,7 @@ int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hip
   s.fd_ntn = make_fastdiv(1);
   s.fd_cb = make_fastdiv(1); s.fd_sbc = make_fastdiv(1);
   s.fast = 1;
+  s.stamp = probs[0].stamp;
   s.c_bytes = s.grp[0].c_bytes;
   if (const char* d = getenv("MMSA_G2_DBG")) s.dbg = atoi(d);
   GemmParams p = probs[0];
