@@ -294,8 +294,14 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
 #pragma unroll
       for (int i = 0; i < NLB; ++i) {
         const RowPix px = decompose_pixel(p.g, k0 + krowB_of(i), p.K);
-        const long src = tap_src(p.g, px, b_ky[i], b_kx[i]);
-        voffB[i] = (src >= 0 && b_coff[i] >= 0) ? (int)((src + b_coff[i]) * 2) : OOB;
+        if (p.g.div == 1) {  // forward-geometry gathers (every weight gradient): 32-bit offsets, unsigned range checks
+          const int sy = px.yb + b_ky[i] * p.g.kmul, sx = px.xb + b_kx[i] * p.g.kmul;
+          const bool ok = b_coff[i] >= 0 && (unsigned)sy < (unsigned)p.g.SH && (unsigned)sx < (unsigned)p.g.SW;
+          voffB[i] = ok ? (((px.img * p.g.SH + sy) * p.g.SW + sx) * (int)p.g.src_pix_stride + b_coff[i]) * 2 : OOB;
+        } else {
+          const long src = tap_src(p.g, px, b_ky[i], b_kx[i]);
+          voffB[i] = (src >= 0 && b_coff[i] >= 0) ? (int)((src + b_coff[i]) * 2) : OOB;
+        }
       }
       d_soffB = 0;
     } else {
