@@ -21,12 +21,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     f32x4 v[NCH];
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = lane + 64 * c;
-      if (ch < nch) {
-        v[c] = Vec4<T>::load(xr + ch * 4);
-        s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
-      }
+    for (int c = 0; c < NCH; ++c) {  // loads are unconditional (clamped chunk, result masked): a branch around each
+      const int ch = lane + 64 * c;   // load makes hipcc wait for every chunk separately — serial memory round trips
+      const f32x4 t = Vec4<T>::load(xr + min(ch, nch - 1) * 4);
+      v[c] = ch < nch ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
     }
     const float mean = wave_sum(s) / (float)H;
     float q = 0.f;
@@ -47,13 +46,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + 64 * c;
-      if (ch < nch) {
-        const f32x4 g = *(const f32x4*)(gamma + ch * 4), b = *(const f32x4*)(beta + ch * 4);
-        f32x4 o;
+      const int chc = min(ch, nch - 1);
+      const f32x4 g = *(const f32x4*)(gamma + chc * 4), b = *(const f32x4*)(beta + chc * 4);
+      f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
-        Vec4<T>::store(yr + ch * 4, o);
-      }
+      for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
+      if (ch < nch) Vec4<T>::store(yr + ch * 4, o);
     }
   }
 }
@@ -86,8 +84,8 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + 64 * c;
-      xvA[c] = f32x4{0, 0, 0, 0}; dvA[c] = f32x4{0, 0, 0, 0};
-      if (ch < nch && okA) { xvA[c] = Vec4<T>::load(xrA + ch * 4); dvA[c] = Vec4<T>::load(drA + ch * 4); }
+      const int chc = min(ch, nch - 1);  // unconditional loads (clamped), masked below: no branch per chunk
+      xvA[c] = Vec4<T>::load(xrA + chc * 4); dvA[c] = Vec4<T>::load(drA + chc * 4);
     }
     const int rowB = rowb + rstride;
     const bool okB = rowB < M;
@@ -98,25 +96,26 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + 64 * c;
-      xvB[c] = f32x4{0, 0, 0, 0}; dvB[c] = f32x4{0, 0, 0, 0};
-      if (ch < nch && okB) { xvB[c] = Vec4<T>::load(xrB + ch * 4); dvB[c] = Vec4<T>::load(drB + ch * 4); }
+      const int chc = min(ch, nch - 1);  // unconditional loads (clamped), masked below: no branch per chunk
+      xvB[c] = Vec4<T>::load(xrB + chc * 4); dvB[c] = Vec4<T>::load(drB + chc * 4);
     }
     f32x4 xhA[NCH], ggA[NCH];
     float s1A = 0.f, s2A = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + 64 * c;
-      xhA[c] = f32x4{0, 0, 0, 0}; ggA[c] = f32x4{0, 0, 0, 0};
-      if (ch < nch && okA) {
-        const f32x4 g = *(const f32x4*)(gamma + ch * 4);
+      {
+        const f32x4 g = *(const f32x4*)(gamma + min(ch, nch - 1) * 4);
+        const float live = (ch < nch && okA) ? 1.f : 0.f;  // dead chunk / row past the end: contributes zeros
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+          const float dvl = dvA[c][e] * live;
           xhA[c][e] = (xvA[c][e] - muA) * rsA;
-          ggA[c][e] = dvA[c][e] * g[e];
+          ggA[c][e] = dvl * g[e];
           s1A += ggA[c][e];
           s2A += ggA[c][e] * xhA[c][e];
-          ag[c][e] += dvA[c][e] * xhA[c][e];
-          ab[c][e] += dvA[c][e];
+          ag[c][e] += dvl * xhA[c][e];
+          ab[c][e] += dvl;
         }
       }
     }
@@ -125,17 +124,18 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + 64 * c;
-      xhB[c] = f32x4{0, 0, 0, 0}; ggB[c] = f32x4{0, 0, 0, 0};
-      if (ch < nch && okB) {
-        const f32x4 g = *(const f32x4*)(gamma + ch * 4);
+      {
+        const f32x4 g = *(const f32x4*)(gamma + min(ch, nch - 1) * 4);
+        const float live = (ch < nch && okB) ? 1.f : 0.f;  // dead chunk / row past the end: contributes zeros
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+          const float dvl = dvB[c][e] * live;
           xhB[c][e] = (xvB[c][e] - muB) * rsB;
-          ggB[c][e] = dvB[c][e] * g[e];
+          ggB[c][e] = dvl * g[e];
           s1B += ggB[c][e];
           s2B += ggB[c][e] * xhB[c][e];
-          ag[c][e] += dvB[c][e] * xhB[c][e];
-          ab[c][e] += dvB[c][e];
+          ag[c][e] += dvl * xhB[c][e];
+          ab[c][e] += dvl;
         }
       }
     }
