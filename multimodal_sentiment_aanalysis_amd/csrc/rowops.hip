@@ -266,9 +266,9 @@ int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* bet
   return MMSA_OK;
 }
 
-// one wave per row, 8 waves per workgroup, up to 512 workgroups (2 per CU = 16 waves per CU: with 256 x 4 waves the
+// one wave per row, 8 waves per workgroup, up to 256 workgroups (one per CU, 8 waves; fewer partial rows for the finalize: with 256 x 4 waves the
 // kernel ran one wave per SIMD and streamed at 1.5 TB/s)
-#define LN_BWD_BLOCKS 512
+#define LN_BWD_BLOCKS 256
 #define LN_BWD_WAVES 8
 size_t layernorm_bwd_ws_bytes(int H) { return (size_t)LN_BWD_BLOCKS * 3 * H * sizeof(float); }
 
