@@ -28,7 +28,7 @@ static GemmParams to_params(const mmsa_gemm_desc* d) {
   p.mul = d->mul; p.ldmul = d->ldmul; p.add = d->add; p.ldadd = d->ldadd;
   p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.split_k = d->split_k; p.ws = d->ws; p.ws_bytes = 0;
   p.zero_page = nullptr;
-  p.a_bytes = p.b_bytes = 0; p.use_srd = 0; p.stamp = nullptr;
+  p.a_bytes = p.b_bytes = 0; p.use_srd = 0; p.stamp = nullptr; p.c_gw = 0; p.c_gh = 0;
   return p;
 }
 

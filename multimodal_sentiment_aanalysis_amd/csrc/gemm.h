@@ -64,6 +64,13 @@ struct GemmParams {
   // optional in-kernel timing record {min start, max end} in s_memrealtime ticks (100 MHz), filled by the MFMA kernels
   // and the split-K reducer when non-null (bench.py roofline: HIP event pairs add ~12 us of queue drain per launch)
   unsigned long long* stamp;
+  // optional output row map (bf16 plain-store epilogue of the persistent kernel only): row m = (img, y, x) of a
+  // c_gh x c_gw grid is stored at element offset img * c_imgpitch + y * c_rowpitch + x * c_colpitch (+ n) instead of
+  // m * ldc. Used by the data gradient of a strided 1x1 convolution: a dense GEMM over the (4x fewer) output-gradient
+  // rows scattered to the even pixels of a zero-filled input gradient. c_gw == 0: no map.
+  int c_gw, c_gh;
+  long c_imgpitch, c_rowpitch, c_colpitch;
+  FastDiv fd_c_ghw, fd_c_gw;
 };
 
 int gemm_bf16_launch(const GemmParams& p, hipStream_t st);

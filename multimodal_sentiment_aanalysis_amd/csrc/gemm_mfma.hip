@@ -533,6 +533,7 @@ static int gemm_bf16_launch_inner(const GemmParams& pin, hipStream_t st) {
       return gemm2_launch(p, p.split_k > 1 || p.ws_bytes > 0 ? avail : 0, st);
     }
   }
+  if (p.c_gw > 0) return MMSA_ERR_UNSUPPORTED;  // output row maps exist in the persistent kernel only
   p.zero_page = mmsa_zero_page();
   if (!p.zero_page) return MMSA_ERR_LAUNCH;
   {

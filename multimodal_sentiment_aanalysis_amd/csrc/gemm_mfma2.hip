@@ -405,6 +405,13 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
 #pragma unroll
         for (int i = 0; i < 4; i += 2) {
           const int m = mrow + i * 16;
+          long rowoff = (long)m * eldc;
+          if (p.c_gw > 0) {  // output row map (strided 1x1 data gradient): (img, y, x) -> scattered row
+            const uint32_t img = fd_div((uint32_t)m, p.fd_c_ghw);
+            const uint32_t rem = (uint32_t)m - img * (uint32_t)(p.c_gh * p.c_gw);
+            const uint32_t yy = fd_div(rem, p.fd_c_gw), xx = rem - yy * (uint32_t)p.c_gw;
+            rowoff = (long)img * p.c_imgpitch + (long)yy * p.c_rowpitch + (long)xx * p.c_colpitch;
+          }
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             const int n = ncol + j * 16;
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
             const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)xi[0], (unsigned)yi[0], false, false);
             const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)xi[1], (unsigned)yi[1], false, false);
             const i32x4 d = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
-            const int vo = (m < eM && n < eN) ? (int)(((long)m * eldc + n) * 2) : OOB;
+            const int vo = (m < eM && n < eN) ? (int)((rowoff + n) * 2) : OOB;
             __builtin_amdgcn_raw_buffer_store_b128(d, rsrcC, vo, 0, 0);
           }
         }
@@ -799,7 +806,12 @@ bool gemm2_eligible(const GemmParams& p) {
   // tile origins may start up to one tile past the last row: keep every scalar + vector offset a positive int32
   const long slack = 2L * 256 * (p.lda > p.ldb ? p.lda : p.ldb) + 65536;
   if (ea + slack >= 0x7FFFFFF0L || eb + slack >= 0x7FFFFFF0L) return false;
-  const long ec = ((long)(p.M - 1) * p.ldc + p.N) * (p.out_f32 ? 4 : 2);
+  long ec = ((long)(p.M - 1) * p.ldc + p.N) * (p.out_f32 ? 4 : 2);
+  if (p.c_gw > 0) {  // mapped output: plain bf16 store only
+    if (p.out_f32 || p.bias || p.C2 || p.mul || p.add || p.act != MMSA_ACT_NONE || p.c_gh <= 0) return false;
+    if (p.M % ((long)p.c_gh * p.c_gw)) return false;
+    ec = ((long)(p.M / ((long)p.c_gh * p.c_gw)) * p.c_imgpitch) * 2;
+  }
   if (ec >= 0x7FFFFFF0L) return false;
   return true;
 }
@@ -899,6 +911,7 @@ static int g2_launch_nj(const GemmParams& p, const G2Sched& s, int grid, hipStre
 int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   GemmParams p = pin;
   const int cus = g2_num_cus();
+  if (p.c_gw > 0) { ws_bytes_avail = 0; p.split_k = 1; }  // mapped output rows: no K split
   if (p.split_k < 1) p.split_k = 1;
   if (p.split_k > 1 && !p.ws) return MMSA_ERR_ARG;
   G2Plan plan = g2_plan(p, cus, ws_bytes_avail);
@@ -950,6 +963,10 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   s.stamp = p.stamp;
   if (const char* d = getenv("MMSA_G2_DBG")) s.dbg = atoi(d);
   s.c_bytes = s.split_k > 1 ? (unsigned)slab_bytes : (unsigned)(((long)(p.M - 1) * p.ldc + p.N) * (p.out_f32 ? 4 : 2));
+  if (p.c_gw > 0) {
+    if (s.split_k > 1) return MMSA_ERR_UNSUPPORTED;
+    s.c_bytes = (unsigned)(((long)(p.M / ((long)p.c_gh * p.c_gw)) * p.c_imgpitch) * 2);
+  }
   {
     long ea, eb;
     g2_extents(p, &ea, &eb);

@@ -190,6 +190,7 @@ template <typename T>
 static int simt_launch(const GemmParams& pin, hipStream_t st) {
   GemmParams p = pin;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MMSA_ERR_ARG;
+  if (p.c_gw > 0) return MMSA_ERR_UNSUPPORTED;
   if (p.split_k < 1) p.split_k = 1;
   if (p.split_k > 1 && (!p.ws || (p.N % 4))) return MMSA_ERR_ARG;
   dim3 grid(cdiv(p.M, SBM) * cdiv(p.N, SBN), p.split_k, 1);

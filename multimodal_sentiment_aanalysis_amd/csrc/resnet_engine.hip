@@ -193,6 +193,25 @@ static int conv_fwd(const ResCtx& r, const ConvDef& c, const void* x, void* z) {
 // dx[B*Hi*Wi][Cin] = conv_transpose(dz) (+ add)
 static int conv_dgrad(const ResCtx& r, const ConvDef& c, const void* dz, void* dx, const void* add) {
   const int B = r.c.batch, M = B * c.Hin * c.Win, K = c.k * c.k * c.Cout;
+  // Strided 1x1 (the downsample branch): only the pixels (s*y, s*x) receive gradient. As a row gather over all
+  // Hin*Win pixels 3/4 of the MFMA rows multiply zeros; instead: zero-fill dx, then a dense GEMM over the Hout*Wout
+  // output-gradient rows whose plain-store epilogue scatters each row to its pixel (GemmParams c_gw..c_colpitch).
+  if (c.k == 1 && c.stride > 1 && c.pad == 0 && !add && r.c.dtype == MMSA_BF16 && !Eng::force_simt() && !Eng::v1_only() &&
+      c.Hin == c.Hout * c.stride && c.Win == c.Wout * c.stride) {
+    GemmParams p = Eng::blank();
+    p.A = dz; p.lda = c.Cout; p.B = r.W(c.w); p.ldb = c.Cin; p.b_kmajor = 1; p.C = dx; p.ldc = c.Cin;
+    p.M = B * c.Hout * c.Wout; p.N = c.Cin; p.K = c.Cout;
+    p.c_gw = c.Wout; p.c_gh = c.Hout;
+    p.c_imgpitch = (long)c.Hin * c.Win * c.Cin;
+    p.c_rowpitch = (long)c.stride * c.Win * c.Cin;
+    p.c_colpitch = (long)c.stride * c.Cin;
+    p.fd_c_ghw = make_fastdiv((uint32_t)(c.Hout * c.Wout));
+    p.fd_c_gw = make_fastdiv((uint32_t)c.Wout);
+    if (gemm2_eligible(p)) {
+      if (hipMemsetAsync(dx, 0, (size_t)M * c.Cin * r.es, r.e.st) != hipSuccess) return MMSA_ERR_LAUNCH;
+      return gemm_bf16_launch(p, r.e.st);
+    }
+  }
   GemmParams p = Eng::blank();
   p.A = dz; p.lda = c.Cout; p.B = r.W(c.w); p.ldb = (long)c.k * c.k * c.Cin; p.b_kmajor = 1; p.C = dx; p.ldc = c.Cin;
   p.M = M; p.N = c.Cin; p.K = K;
