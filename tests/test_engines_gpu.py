@@ -57,19 +57,22 @@ def _check_grads(got, ref, tol, what, skip=(), l2=False):
 
 
 @pytest.mark.parametrize("precision,pol,tol_f,tol_g", [("fp32", FP32, 2e-5, 2e-4), ("bf16", BF16, 2e-2, 6e-2)])
-@pytest.mark.parametrize("B,S,masked", [(4, 32, False), (3, 16, True), (2, 64, True)])
+# S = 128 is the benchmark sequence length (MFMA attention both ways); S = 256 is BASELINE.json configs[3]
+# (MFMA attention forward, the backward falls back to the SIMT kernel)
+@pytest.mark.parametrize("B,S,masked", [(4, 32, False), (3, 16, True), (2, 64, True), (2, 128, True), (1, 256, False)])
 def test_bert_engine(dev, precision, pol, tol_f, tol_g, B, S, masked):
     torch.manual_seed(0)
-    net = BertTextNet(MINI_BERT)
+    cfg = MINI_BERT if S <= MINI_BERT["max_pos"] else dict(MINI_BERT, max_pos=256)
+    net = BertTextNet(cfg)
     net.precision = precision
     sd = cpu_state(net)
-    _, ids, mask, _ = synth_batch(B, S, 32, 32, MINI_BERT["vocab"], seed=5)
+    _, ids, mask, _ = synth_batch(B, S, 32, 32, cfg["vocab"], seed=5)
     if masked:
         mask[:, S - 5:] = 0
     wgt = torch.randn(B, 256, generator=torch.Generator().manual_seed(9))
 
     def feat_fn(work):
-        _, pooled = bert_forward(work, "bert.", ids, mask if masked else None, MINI_BERT, pol)
+        _, pooled = bert_forward(work, "bert.", ids, mask if masked else None, cfg, pol)
         return pooled @ pol.q(work["proj.weight"]).t() + work["proj.bias"]
 
     ref = feat_fn(sd)
