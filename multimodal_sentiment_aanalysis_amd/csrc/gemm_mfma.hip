@@ -376,7 +376,7 @@ static int launch_variant(const GemmParams& p, hipStream_t st) {
 }
 
 // ---- optional live timing of the MFMA GEMM launches (bench.py roofline): HIP events on the launch stream ----------
-struct ProfRec { hipEvent_t a, b; double flop; int M, N, K, akm, bkm, gather, split; };
+struct ProfRec { hipEvent_t a, b; double flop; int M, N, K, akm, bkm, gather, split, wm, nj, ksplit, epi; };
 static unsigned long long* g_stamp_dev = nullptr;  // [record][2]: in-kernel {min start, max end} ticks
 static size_t g_stamp_cap = 0;
 static int g_prof_mode = 0;  // 0: HIP events around each launch; 1: in-kernel clock stamps (no events)
@@ -454,11 +454,12 @@ int gemm_prof_end(double* total_ms, double* total_flop, long* launches) {
   *total_ms = ms; *total_flop = fl; *launches = (long)g_prof_used;
   if (const char* path = getenv("MMSA_PROF_DUMP")) {  // per-launch table for the profiles/ directory
     if (FILE* f = fopen(path, "w")) {
-      fprintf(f, "M,N,K,a_kmajor,b_kmajor,gather,split_k,us,tflops\n");
+      fprintf(f, "M,N,K,a_kmajor,b_kmajor,gather,split_k,us,tflops,tile,ksplit,epilogue\n");
       for (size_t i = 0; i < g_prof_used; ++i) {
         const ProfRec& r = g_prof[i];
-        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.1f\n", r.M, r.N, r.K, r.akm, r.bkm, r.gather, r.split, dur[i] * 1e3,
-                dur[i] > 0 ? r.flop / (dur[i] * 1e-3) / 1e12 : 0.0);
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.1f,%dx%d,%d,%s\n", r.M, r.N, r.K, r.akm, r.bkm, r.gather, r.split, dur[i] * 1e3,
+                dur[i] > 0 ? r.flop / (dur[i] * 1e-3) / 1e12 : 0.0, r.wm * 64, r.nj * 16 * (r.wm ? 8 / r.wm : 0), r.ksplit,
+                r.epi == 0 ? "store" : r.epi == 1 ? "bias/act" : "side");
       }
       fclose(f);
     }
@@ -474,15 +475,20 @@ int gemm_bf16_launch(const GemmParams& pin, hipStream_t st) {
   ProfRec& r = g_prof[g_prof_used];
   r.flop = 2.0 * pin.M * pin.N * (double)pin.K;
   r.M = pin.M; r.N = pin.N; r.K = pin.K; r.akm = pin.a_kmajor; r.bkm = pin.b_kmajor; r.gather = pin.gather; r.split = pin.split_k;
+  r.epi = (pin.mul || pin.add) ? 2 : (pin.bias || pin.C2 || pin.act != MMSA_ACT_NONE) ? 1 : 0;
+  g2_last_plan[0] = g2_last_plan[1] = g2_last_plan[2] = 0;
   if (g_prof_mode == 1) {  // in-kernel clock stamps: nothing is put into the queue around the launch
     GemmParams p = pin;
     p.stamp = g_stamp_dev + 2 * g_prof_used;
     ++g_prof_used;
-    return gemm_bf16_launch_inner(p, st);
+    const int rc = gemm_bf16_launch_inner(p, st);
+    r.wm = g2_last_plan[0]; r.nj = g2_last_plan[1]; r.ksplit = g2_last_plan[2];
+    return rc;
   }
   (void)hipEventRecord(r.a, st);
   const int rc = gemm_bf16_launch_inner(pin, st);
   (void)hipEventRecord(r.b, st);
+  r.wm = g2_last_plan[0]; r.nj = g2_last_plan[1]; r.ksplit = g2_last_plan[2];
   ++g_prof_used;
   return rc;
 }
@@ -496,18 +502,20 @@ int gemm_bf16_launch_group(const GemmParams* probs, float* const* colsum, int n,
   ProfRec& r = g_prof[g_prof_used];
   r.flop = 0;
   for (int g = 0; g < n; ++g) r.flop += 2.0 * probs[g].M * probs[g].N * (double)probs[g].K;
-  r.M = -n; r.N = 0; r.K = probs[0].K; r.akm = 1; r.bkm = 1; r.gather = 0; r.split = 1;
+  r.M = -n; r.N = 0; r.K = probs[0].K; r.akm = 1; r.bkm = 1; r.gather = 0; r.split = 1; r.epi = 0;
   if (g_prof_mode == 1) {
     GemmParams ps[4];
     for (int g = 0; g < n; ++g) ps[g] = probs[g];
     ps[0].stamp = g_stamp_dev + 2 * g_prof_used;
     const int rc = gemm2_launch_group(ps, colsum, n, st);
+    r.wm = g2_last_plan[0]; r.nj = g2_last_plan[1]; r.ksplit = g2_last_plan[2];
     if (rc != MMSA_ERR_UNSUPPORTED) ++g_prof_used;
     return rc;
   }
   (void)hipEventRecord(r.a, st);
   const int rc = gemm2_launch_group(probs, colsum, n, st);
   if (rc == MMSA_ERR_UNSUPPORTED) return rc;  // nothing was launched: the record is reused by the fallback launches
+  r.wm = g2_last_plan[0]; r.nj = g2_last_plan[1]; r.ksplit = g2_last_plan[2];
   (void)hipEventRecord(r.b, st);
   ++g_prof_used;
   return rc;

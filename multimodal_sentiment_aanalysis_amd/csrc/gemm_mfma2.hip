@@ -816,6 +816,12 @@ bool gemm2_eligible(const GemmParams& p) {
   return true;
 }
 
+int g2_last_plan[3] = {0, 0, 0};  // profiling only (gemm_mfma.hip): tile shape and K split of the latest launch
+
+static inline int g2_epi_class(const GemmParams& p) {
+  return (p.mul || p.add) ? 2 : (p.bias || p.C2 || p.act != MMSA_ACT_NONE || (p.out_f32 && p.accumulate)) ? 1 : 0;
+}
+
 struct G2Plan { int wm, nj, split; };  // wave rows (4: 256-row tile, 2: 128-row tile), column tiles per wave, K split
 static inline int g2_bm(const G2Plan& pl) { return pl.wm * 64; }
 static inline int g2_bn(const G2Plan& pl) { return pl.nj * 16 * (8 / pl.wm); }
@@ -827,13 +833,16 @@ static inline int g2_bn(const G2Plan& pl) { return pl.nj * 16 * (8 / pl.wm); }
 // a split adds the slab round trip at ~4 TB/s and the reducer launch. So: the biggest tile that keeps whole rounds of
 // `cus` workgroups busy, and as many K slices as it takes to fill the chip when there are few tiles (weight
 // gradients: 1..72 tiles with K = 8192..802816).
-static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail) {
+static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail, int force_wm = 0, int force_nj = 0) {
   const int nsteps = p.K / G2_BK;
   G2Plan best{4, 4, 1};
   double best_cost = 1e300;
   static const int cfgs[5][2] = {{4, 4}, {4, 3}, {4, 2}, {2, 2}, {2, 1}};
+  // epilogue class: 0 plain store, 1 bias / activation / side output (registers only), 2 reads gelu' / residual operands
+  const int epi = g2_epi_class(p);
   for (int ci = 0; ci < 5; ++ci) {
     const G2Plan shape{cfgs[ci][0], cfgs[ci][1], 1};
+    if (force_wm && (shape.wm != force_wm || shape.nj != force_nj)) continue;
     const int bm = g2_bm(shape), bn = g2_bn(shape);
     const int ntm = cdiv(p.M, bm), ntn = cdiv(p.N, bn);
     const long tiles = (long)ntm * ntn;
@@ -856,13 +865,19 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
     const int w32 = bn / 32;  // tile width in 32-column units
     const double t_step = shape.wm == 4 ? 1.0 + 0.06 * w32 : 0.72 + 0.05 * w32;
     const double t_item = shape.wm == 4 ? 0.3 + 0.2 * w32 : 0.3 + 0.1 * w32;
+    // the register-only epilogue costs ~1 us per item, the one with side operands one memory round trip more; on the
+    // 256x128 tile both run out of registers (accumulators + side operands + the loop's prefetched fragments: the
+    // compiler spills ~60 VGPRs there), measured +3 / +8 us per item (tools/microbench/bench_small.py, bench_epi2.py)
+    static const double epi_cost[3][5] = {{0, 0, 0, 0, 0}, {3.0, 1.0, 0.9, 0.65, 0.5}, {8.0, 2.0, 1.2, 1.0, 0.8}};
+    static const bool no_epi = [] { const char* v = getenv("MMSA_G2_NOEPI"); return v && atoi(v) != 0; }();  // A/B hook
     const double waste = (double)ntn * bn / p.N * ((double)ntm * bm / p.M);  // padding: only as a tie breaker
     for (int c = 0; c < nc; ++c) {
       const int per = cdiv(nsteps, cand[c]);
       const int split = cdiv(nsteps, per);  // no empty slices: e.g. 3136 steps / 256 -> 13 per slice -> 242 slices
       const long items = tiles * split;
       const long rounds = (items + cus - 1) / cus;
-      double cost = (double)rounds * (per * t_step + t_item) + 1e-3 * waste;
+      // (with a K split the tiles store raw slabs and the reducer applies the epilogue)
+      double cost = (double)rounds * (per * t_step + t_item + (split == 1 && !no_epi ? epi_cost[epi][ci] : 0.0)) + 1e-3 * waste;
       if (split > 1) cost += 3.0 + 2.0 * split * (double)p.M * p.N * 4.0 / 4e6;
       if (cost < best_cost - 1e-9) { best_cost = cost; best = G2Plan{shape.wm, shape.nj, split}; }
     }
@@ -872,12 +887,13 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
 
 // plans are pure functions of the shape: memoize (one caller thread per process — include/mmsa.h)
 static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
-  struct Key { int M, N, K; size_t ws; G2Plan plan; };
+  struct Key { int M, N, K, epi; size_t ws; G2Plan plan; };
   static std::vector<Key> cache;
+  const int epi = g2_epi_class(p);
   for (const Key& k : cache)
-    if (k.M == p.M && k.N == p.N && k.K == p.K && k.ws == ws_bytes_avail) return k.plan;
+    if (k.M == p.M && k.N == p.N && k.K == p.K && k.epi == epi && k.ws == ws_bytes_avail) return k.plan;
   const G2Plan plan = g2_plan_search(p, cus, ws_bytes_avail);
-  if (cache.size() < 4096) cache.push_back(Key{p.M, p.N, p.K, ws_bytes_avail, plan});
+  if (cache.size() < 4096) cache.push_back(Key{p.M, p.N, p.K, epi, ws_bytes_avail, plan});
   return plan;
 }
 
@@ -914,12 +930,20 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   if (p.c_gw > 0) { ws_bytes_avail = 0; p.split_k = 1; }  // mapped output rows: no K split
   if (p.split_k < 1) p.split_k = 1;
   if (p.split_k > 1 && !p.ws) return MMSA_ERR_ARG;
-  G2Plan plan = g2_plan(p, cus, ws_bytes_avail);
-  if (const char* f = getenv("MMSA_G2_NJ")) {  // test hook: "nj" (256-row tile) or "wm:nj"
-    int a = 0, b = 0;
-    const int n = sscanf(f, "%d:%d", &a, &b);
-    if (n == 2 && (a == 4 || a == 2) && b >= 1 && b <= (a == 4 ? 4 : 2) && !(a == 4 && b < 2)) { plan.wm = a; plan.nj = b; }
-    else if (n == 1 && a >= 2 && a <= 4) { plan.wm = 4; plan.nj = a; }
+  G2Plan plan;
+  {
+    int fwm = 0, fnj = 0;
+    if (const char* f = getenv("MMSA_G2_NJ")) {  // test hook: "nj" (256-row tile) or "wm:nj"; the K split is still planned
+      int a = 0, b = 0;
+      const int n = sscanf(f, "%d:%d", &a, &b);
+      if (n == 2 && (a == 4 || a == 2) && b >= 1 && b <= (a == 4 ? 4 : 2) && !(a == 4 && b < 2)) { fwm = a; fnj = b; }
+      else if (n == 1 && a >= 2 && a <= 4) { fwm = 4; fnj = a; }
+    }
+    plan = fwm ? g2_plan_search(p, cus, ws_bytes_avail, fwm, fnj) : g2_plan(p, cus, ws_bytes_avail);
+  }
+  if (const char* f = getenv("MMSA_G2_SPLIT")) {  // test hook: force the K split (needs a workspace that holds it)
+    const int sp = atoi(f);
+    if (sp >= 1 && sp <= p.K / G2_BK && (sp == 1 || (p.ws && (size_t)sp * p.M * p.N * 4 <= ws_bytes_avail))) plan.split = sp;
   }
   const long slab_bytes = (long)plan.split * p.M * p.N * 4;
   if (plan.split > 1 && slab_bytes >= 0x7FFFFFF0L) plan.split = 1;
@@ -977,6 +1001,7 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
       if (atoi(nl)) { p.a_bytes = 0; p.b_bytes = 0; }
   }
   const int grid = (int)(s.items < cus ? s.items : cus);
+  g2_last_plan[0] = plan.wm; g2_last_plan[1] = plan.nj; g2_last_plan[2] = s.split_k;
   int rc;
   if (plan.wm == 4) {
     if (plan.nj == 4) rc = g2_launch_nj<4, 4>(p, s, grid, st);
@@ -1052,6 +1077,7 @@ int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hip
   p.split_k = 1;
   p.a_bytes = s.grp[0].a_bytes; p.b_bytes = s.grp[0].b_bytes;
   const int grid = tiles < cus ? tiles : cus;
+  g2_last_plan[0] = plan.wm; g2_last_plan[1] = plan.nj; g2_last_plan[2] = 1;
   if (plan.nj == 4) return g2_launch_t<4, 4, true, true, 0>(p, s, grid, st);
   if (plan.nj == 3) return g2_launch_t<4, 3, true, true, 0>(p, s, grid, st);
   return g2_launch_t<4, 2, true, true, 0>(p, s, grid, st);

@@ -53,9 +53,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
                                                     const float* __restrict__ norm_clip, float grad_scale) {
   const float coef = (norm_clip ? norm_clip[1] : 1.f) * grad_scale;
   const long n4 = n / 4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    f32x4 wv = *(const f32x4*)(w + i * 4), mv = *(const f32x4*)(m + i * 4), vv = *(const f32x4*)(v + i * 4);
-    const f32x4 gv = *(const f32x4*)(g + i * 4) * coef;
+  // every stream is touched once per step (540 MB each: nothing survives in L2 / MALL until its next use), so all
+  // fp32 accesses are non-temporal; two independent float4 groups per thread keep 8 loads in flight
+  auto upd = [&](f32x4& wv, f32x4& mv, f32x4& vv, f32x4 gv) __attribute__((always_inline)) {
+    gv = gv * coef;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       wv[e] *= 1.f - lr * wd;
@@ -63,13 +64,30 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
       vv[e] = b2 * vv[e] + (1.f - b2) * gv[e] * gv[e];
       wv[e] -= (lr / bc1) * mv[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
     }
-    *(f32x4*)(w + i * 4) = wv;
-    *(f32x4*)(m + i * 4) = mv;
-    *(f32x4*)(v + i * 4) = vv;
+  };
+  auto ld = [&](const float* q, long i) __attribute__((always_inline)) -> f32x4 { return __builtin_nontemporal_load((const f32x4*)(q + i * 4)); };
+  auto st = [&](float* q, long i, f32x4 x) __attribute__((always_inline)) { __builtin_nontemporal_store(x, (f32x4*)(q + i * 4)); };
+  auto st16 = [&](long i, f32x4 wv) __attribute__((always_inline)) {
     if (w16) {
       bf16x4 t = {(bf16)wv[0], (bf16)wv[1], (bf16)wv[2], (bf16)wv[3]};
-      *(bf16x4*)(w16 + i * 4) = t;
+      *(bf16x4*)(w16 + i * 4) = t;  // read again by the next forward: regular store
     }
+  };
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const long j = i + stride;
+    f32x4 w0 = ld(w, i), m0 = ld(m, i), v0 = ld(v, i), g0 = ld(g, i);
+    f32x4 w1 = ld(w, j), m1 = ld(m, j), v1 = ld(v, j), g1 = ld(g, j);
+    upd(w0, m0, v0, g0);
+    upd(w1, m1, v1, g1);
+    st(w, i, w0); st(m, i, m0); st(v, i, v0); st16(i, w0);
+    st(w, j, w1); st(m, j, m1); st(v, j, v1); st16(j, w1);
+  }
+  for (; i < n4; i += stride) {
+    f32x4 w0 = ld(w, i), m0 = ld(m, i), v0 = ld(v, i), g0 = ld(g, i);
+    upd(w0, m0, v0, g0);
+    st(w, i, w0); st(m, i, m0); st(v, i, v0); st16(i, w0);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long i = n4 * 4 + threadIdx.x;

@@ -19,7 +19,7 @@ mul.normal_(); add.normal_()
 bias = torch.randn(N, device=dev)
 Bk = rnd(Kd, N)
 print("cfg     plain   bias  bias+gelu  bias+gelu+C2  NN-mul  NT-add")
-for c in ["auto", "4", "3", "2"]:
+for c in ["auto", "4", "3", "2", "2:2"]:
     if c == "auto": os.environ.pop("MMSA_G2_NJ", None)
     else: os.environ["MMSA_G2_NJ"] = c
     t = [bench(lambda: K.gemm(A, B, C, M, N, Kd, Kd, Kd, N)),
