@@ -147,6 +147,7 @@ def main():
     #         GEMM kernels themselves, nothing added to the queue. (b) is what rocprofv3 --kernel-trace reports and what
     #         `roofline.achieved` uses; (a) still carries ~12 us of queue drain per launch and is reported beside it.
     psteps = min(args.steps, 5)
+    STAMP_STEPS = 3  # steps averaged by pass (b); MMSA_PROF_DUMP then holds 3 rows per launch of a step
     ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     ms_ev, fl_ev, n_ev = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     if os.environ.get("MMSA_BENCH_NOPROF", "0") == "0":
@@ -159,12 +160,16 @@ def main():
         sync()
         L.mmsa_prof_end(ctypes.byref(ms_ev), ctypes.byref(fl_ev), ctypes.byref(n_ev))
         L.mmsa_prof_mode(1)
-        L.mmsa_prof_begin(1200)
+        L.mmsa_prof_begin(STAMP_STEPS * 1200)
         sync()
-        trainer.step(*batch)
+        for _ in range(STAMP_STEPS):
+            trainer.step(*batch)
         sync()
         L.mmsa_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
         L.mmsa_prof_mode(0)
+        ms.value /= STAMP_STEPS
+        fl.value /= STAMP_STEPS
+        n.value //= STAMP_STEPS
     el = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -186,8 +191,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_GEMM_LAUNCH,
-                         "kernel": "gemm2_kernel (+ split-K reducer): every MFMA GEMM launch of one step right after the timed "
-                                   "steps (NT/NN/TN, implicit-GEMM convolutions, grouped weight gradients); duration = "
+                         "kernel": "gemm2_kernel (+ split-K reducer): every MFMA GEMM launch of 3 steps right after the "
+                                   "timed steps, averaged per step (NT/NN/TN, implicit-GEMM convolutions, grouped weight gradients); duration = "
                                    "in-kernel clock, first workgroup start to last workgroup end",
                          "launches": n.value, "kernel_ms_per_step": round(ms.value, 3),
                          "achieved_hip_events": round(gemm_tflops_ev, 2),

@@ -14,11 +14,11 @@ static GemmParams to_params(const mmsa_gemm_desc* d) {
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
   p.a_kmajor = d->a_kmajor; p.b_kmajor = d->b_kmajor; p.gather = d->gather;
-  p.b_tap_stride = d->b_tap_stride;
+  p.b_tap_stride = d->b_tap_stride; p.b_tap_stride_y = 0;
   const mmsa_conv_geom& s = d->geom;
   ConvGeom& g = p.g;
   g.SH = s.SH; g.SW = s.SW; g.GH = s.GH; g.GW = s.GW; g.KH = s.KH; g.KW = s.KW;
-  g.mul = s.mul; g.kmul = s.kmul; g.off = s.off; g.div = s.div; g.cper = s.cper;
+  g.mul = s.mul; g.kmul = s.kmul; g.off = s.off; g.offx = s.off; g.div = s.div; g.cper = s.cper;
   g.src_pix_stride = s.src_pix_stride;
   g.fd_gw = make_fastdiv(s.GW > 0 ? s.GW : 1);
   g.fd_ghw = make_fastdiv(s.GH * s.GW > 0 ? s.GH * s.GW : 1);

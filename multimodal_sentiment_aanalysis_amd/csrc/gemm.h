@@ -16,6 +16,8 @@
 //                data grad   : mul = 1, kmul = -1, off = +pad, div = stride  (source = dY)
 //                With gather = 1 and b_kmajor = 1 the B row of k is (k % cper) * ldb + (k / cper) * b_tap_stride
 //                (weight [Cout][taps][Cin] read as [k = (tap, cout)][n = cin]).
+//                parity class of a stride-2 data grad: see conv_dgrad (resnet_engine.hip): a stride-1 gather over the
+//                class's own taps (off / offx = the class parities, tap strides 2x the whole filter's).
 //   gather = 2 : B (k-major) rows (k) are output pixels, columns n = tap*cper + c; source as forward conv above
 //                (weight gradient: dW[cout][tap][cin] = sum_pixels dY[pixel][cout] * X[shifted pixel][cin]).
 #pragma once
@@ -26,6 +28,7 @@ struct ConvGeom {
   int GH, GW;           // row-space grid (rows -> (img, y, x))
   int KH, KW;
   int mul, kmul, off, div;
+  int offx;             // the x offset (off is the y offset; equal for whole convolutions, different for parity classes)
   int cper;             // channels per tap along K (gather=1) or along N (gather=2)
   long src_pix_stride;  // elements between consecutive source pixels
   FastDiv fd_gw, fd_ghw, fd_kw, fd_cper;
@@ -40,6 +43,7 @@ struct GemmParams {
   int a_kmajor, b_kmajor;
   int gather;
   long b_tap_stride;
+  long b_tap_stride_y;    // element stride of a tap row (0: KW * b_tap_stride); tap (ky, kx) sits at ky * this + kx * b_tap_stride
   ConvGeom g;
   // epilogue: v = acc (+ bias[n]); C2 = v (optional, storage type); v = act(v); v *= gelu'(mul[m][n]) (optional);
   //           v += add[m][n] (optional); C = v (storage type, or fp32 when out_f32; += when accumulate)
@@ -72,6 +76,11 @@ struct GemmParams {
   long c_imgpitch, c_rowpitch, c_colpitch;
   FastDiv fd_c_ghw, fd_c_gw;
 };
+
+// element offset of filter tap (ky, kx) in the k-major weight view of a gather = 1 data gradient
+__host__ __device__ __forceinline__ long b_tap_offset(const GemmParams& p, int ky, int kx) {
+  return (long)ky * (p.b_tap_stride_y ? p.b_tap_stride_y : (long)p.g.KW * p.b_tap_stride) + (long)kx * p.b_tap_stride;
+}
 
 int gemm_bf16_launch(const GemmParams& p, hipStream_t st);
 bool gemm2_eligible(const GemmParams& p);

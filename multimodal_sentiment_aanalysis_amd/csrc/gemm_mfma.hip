@@ -170,7 +170,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
       if constexpr (GATHER == 1) {  // weight [cout][tap][cin] read as rows k = (tap, cout)
         const uint32_t tap = fd_div((uint32_t)k0, p.g.fd_cper);
         kbase = k0 - (int)tap * p.g.cper;
-        tapoff = (long)tap * p.b_tap_stride;
+        const int tky = (int)fd_div(tap, p.g.fd_kw);
+        tapoff = b_tap_offset(p, tky, (int)tap - tky * p.g.KW);
       }
       const int k = k0 + krowi[i];
       return (b_coloff[i] >= 0 && k < kend) ? Bb + (long)(kbase + krowi[i]) * p.ldb + tapoff + b_coloff[i] : zp;

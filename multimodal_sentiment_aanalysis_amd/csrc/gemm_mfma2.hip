@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       }
       d_soffA = c0 * 2;
       if constexpr (B_KM)  // weight [cout][tap][cin] read as k-major rows k = (tap, cout): row (k % cper), tap offset
-        d_soffB = (int)(((long)c0 * lldb + (long)tap * p.b_tap_stride + L.n0) * 2);
+        d_soffB = (int)(((long)c0 * lldb + b_tap_offset(p, ky, kx) + L.n0) * 2);
       else
         d_soffB = (int)(((long)L.n0 * lldb + k0) * 2);
     } else if constexpr (GATHER == 2) {
@@ -769,6 +769,14 @@ static int g2_num_cus() {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
     if (n <= 0) n = 256;
+    // MMSA_G2_CUS=<n>: cap the persistent grid, leaving CUs to kernels of other streams (a workgroup of this kernel
+    // fills its CU's register file and LDS, so e.g. RCCL's blocks cannot co-reside with it: data-parallel runs that
+    // overlap the gradient all-reduce with the backward can reserve the collective's CUs instead of having a second
+    // round of tiles wait for them)
+    if (const char* c = getenv("MMSA_G2_CUS")) {
+      const int cap = atoi(c);
+      if (cap >= 8 && cap < n) n = cap;
+    }
   }
   return n;
 }
@@ -781,7 +789,7 @@ static void g2_extents(const GemmParams& p, long* ea, long* eb) {
   if (p.gather == 1) *ea = (long)(p.M / (ghw > 0 ? ghw : 1)) * p.g.SH * p.g.SW * p.g.src_pix_stride * 2;  // source activation
   if (p.gather == 2) *eb = (long)(p.K / (ghw > 0 ? ghw : 1)) * p.g.SH * p.g.SW * p.g.src_pix_stride * 2;
   if (p.gather == 1 && p.b_kmajor)  // weight [cout][taps][cin] addressed through (k % cper) * ldb + tap * b_tap_stride
-    *eb = ((long)(p.g.cper - 1) * p.ldb + (long)(p.g.KH * p.g.KW - 1) * p.b_tap_stride + p.N) * 2;
+    *eb = ((long)(p.g.cper - 1) * p.ldb + b_tap_offset(p, p.g.KH - 1, p.g.KW - 1) + p.N) * 2;
 }
 
 bool gemm2_eligible(const GemmParams& p) {
@@ -829,7 +837,8 @@ static inline int g2_bn(const G2Plan& pl) { return pl.nj * 16 * (8 / pl.wm); }
 // Tile shape and K split. Cost model in microseconds, calibrated on MI355X (profiles/): a K step of the 256-row tile
 // costs about the same for every width (the 32 KiB A tile, the barrier and the LDS traffic dominate; MFMA-only time is
 // 0.19 us per 32 columns): t_step = 1.0 + 0.06 nj; per item 0.3 + 0.2 nj (pipeline bubble + epilogue stores);
-// the 128-row tile moves 2/3 of the bytes and half of the MFMAs per step: t_step = 0.72 + 0.06 nj per 64 columns;
+// the 128-row tile moves 2/3 of the bytes and half of the MFMAs per step: t_step = 0.42 + 0.07 per 32 columns
+// (in situ: 3136x512x2048 at 128x128 0.70 us / step, at 128x64 0.56);
 // a split adds the slab round trip at ~4 TB/s and the reducer launch. So: the biggest tile that keeps whole rounds of
 // `cus` workgroups busy, and as many K slices as it takes to fill the chip when there are few tiles (weight
 // gradients: 1..72 tiles with K = 8192..802816).
@@ -863,7 +872,7 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
         if (d > 1 && d <= smax && nc < 16) cand[nc++] = (int)d;
     }
     const int w32 = bn / 32;  // tile width in 32-column units
-    const double t_step = shape.wm == 4 ? 1.0 + 0.06 * w32 : 0.72 + 0.05 * w32;
+    const double t_step = shape.wm == 4 ? 1.0 + 0.06 * w32 : 0.42 + 0.07 * w32;
     const double t_item = shape.wm == 4 ? 0.3 + 0.2 * w32 : 0.3 + 0.1 * w32;
     // the register-only epilogue costs ~1 us per item, the one with side operands one memory round trip more; on the
     // 256x128 tile both run out of registers (accumulators + side operands + the loop's prefetched fragments: the

@@ -17,7 +17,7 @@ __device__ __forceinline__ long simt_tap_src(const ConvGeom& g, int pix, int ky,
   const int ghw = g.GH * g.GW;
   const int img = pix / ghw, rem = pix - img * ghw;
   const int y = rem / g.GW, x = rem - y * g.GW;
-  int sy = y * g.mul + g.off + ky * g.kmul, sx = x * g.mul + g.off + kx * g.kmul;
+  int sy = y * g.mul + g.off + ky * g.kmul, sx = x * g.mul + g.offx + kx * g.kmul;
   if (g.div > 1) {
     if (sy < 0 || sx < 0 || sy % g.div || sx % g.div) return -1;
     sy /= g.div; sx /= g.div;
@@ -51,7 +51,8 @@ __device__ __forceinline__ float simt_load_b(const GemmParams& p, int k, int n, 
   }
   if (p.gather == 1 && p.b_kmajor) {
     const int tap = k / p.g.cper, c = k - tap * p.g.cper;
-    return to_f32<T>(B[(long)c * p.ldb + (long)tap * p.b_tap_stride + n]);
+    const int ky = tap / p.g.KW, kx = tap - ky * p.g.KW;
+    return to_f32<T>(B[(long)c * p.ldb + b_tap_offset(p, ky, kx) + n]);
   }
   return to_f32<T>(p.b_kmajor ? B[(long)k * p.ldb + n] : B[(long)n * p.ldb + k]);
 }

@@ -54,7 +54,7 @@ __device__ __forceinline__ RowPix decompose_pixel(const ConvGeom& g, int m, int 
   const uint32_t x = rem - y * (uint32_t)g.GW;
   r.img = (int)img;
   r.yb = (int)y * g.mul + g.off;
-  r.xb = (int)x * g.mul + g.off;
+  r.xb = (int)x * g.mul + g.offx;
   return r;
 }
 

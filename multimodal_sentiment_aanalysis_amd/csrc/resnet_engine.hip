@@ -174,7 +174,7 @@ struct ResCtx {
 
 static void set_geom(ConvGeom& g, int SH, int SW, int GH, int GW, int k, int mul, int kmul, int off, int div, int cper) {
   g.SH = SH; g.SW = SW; g.GH = GH; g.GW = GW; g.KH = k; g.KW = k;
-  g.mul = mul; g.kmul = kmul; g.off = off; g.div = div; g.cper = cper; g.src_pix_stride = cper;
+  g.mul = mul; g.kmul = kmul; g.off = off; g.offx = off; g.div = div; g.cper = cper; g.src_pix_stride = cper;
   g.fd_gw = make_fastdiv(GW); g.fd_ghw = make_fastdiv(GH * GW); g.fd_kw = make_fastdiv(k); g.fd_cper = make_fastdiv(cper);
 }
 
@@ -210,6 +210,45 @@ static int conv_dgrad(const ResCtx& r, const ConvDef& c, const void* dz, void* d
     if (gemm2_eligible(p)) {
       if (hipMemsetAsync(dx, 0, (size_t)M * c.Cin * r.es, r.e.st) != hipSuccess) return MMSA_ERR_LAUNCH;
       return gemm_bf16_launch(p, r.e.st);
+    }
+  }
+  // Strided 3x3 (stride 2, pad 1: conv2 of the first block of stages 2-4). As one row gather over all Hin*Win pixels,
+  // 3/4 of the (pixel, tap) pairs are stride holes that multiply zeros. Decomposed by pixel parity (py, px) = (y % 2,
+  // x % 2): the pixels of a class only see the taps with ky = py + 1 (mod 2), kx likewise — 1, 2, 2 and 4 taps — and
+  // for those the source is a plain stride-1 gather of dY: sy = y' + py - ky' with y = 2y' + py and ky = 2ky' (py = 1)
+  // or ky = 1 (py = 0). Four GEMMs over a quarter of the rows each, 9 taps in total, instead of 9 taps on every row:
+  // 4x fewer MFMAs. Each class stores through the output row map to its own pixels; together they cover dx once.
+  if (c.k == 3 && c.stride == 2 && c.pad == 1 && !add && r.c.dtype == MMSA_BF16 && !Eng::force_simt() && !Eng::v1_only() &&
+      c.Hin == 2 * c.Hout && c.Win == 2 * c.Wout && !getenv("MMSA_NO_PARITY_DGRAD")) {
+    GemmParams ps[4];
+    bool ok = true;
+    for (int cls = 0; cls < 4; ++cls) {
+      const int py = cls >> 1, px = cls & 1;
+      const int kh = py ? 2 : 1, kw = px ? 2 : 1, ky0 = py ? 0 : 1, kx0 = px ? 0 : 1;
+      GemmParams& p = ps[cls];
+      p = Eng::blank();
+      p.A = dz; p.lda = c.Cout;
+      p.B = (const char*)r.W(c.w) + (size_t)(ky0 * 3 + kx0) * c.Cin * r.es;
+      p.ldb = 9L * c.Cin; p.b_kmajor = 1; p.b_tap_stride = 2L * c.Cin; p.b_tap_stride_y = 6L * c.Cin;
+      p.C = (char*)dx + (size_t)(py * c.Win + px) * c.Cin * r.es; p.ldc = c.Cin;
+      p.M = B * c.Hout * c.Wout; p.N = c.Cin; p.K = kh * kw * c.Cout;
+      p.gather = 1;
+      set_geom(p.g, c.Hout, c.Wout, c.Hout, c.Wout, 1, 1, -1, py, 1, c.Cout);
+      p.g.KH = kh; p.g.KW = kw; p.g.offx = px; p.g.fd_kw = make_fastdiv((uint32_t)kw);
+      p.c_gw = c.Wout; p.c_gh = c.Hout;
+      p.c_imgpitch = (long)c.Hin * c.Win * c.Cin;
+      p.c_rowpitch = 2L * c.Win * c.Cin;
+      p.c_colpitch = 2L * c.Cin;
+      p.fd_c_ghw = make_fastdiv((uint32_t)(c.Hout * c.Wout));
+      p.fd_c_gw = make_fastdiv((uint32_t)c.Wout);
+      ok = ok && gemm2_eligible(p);
+    }
+    if (ok) {
+      for (int cls = 0; cls < 4; ++cls) {
+        const int rc = gemm_bf16_launch(ps[cls], r.e.st);
+        if (rc) return rc;
+      }
+      return MMSA_OK;
     }
   }
   GemmParams p = Eng::blank();

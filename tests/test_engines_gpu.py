@@ -3,12 +3,15 @@
 fp32 storage mode must match the fp32 oracle tightly (accumulation order only); bf16 mode is compared with the
 oracle run under the bf16 storage policy (same rounding points) and, loosely, with the fp32 oracle.
 """
+import ctypes
+
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
 import multimodal_sentiment_aanalysis_amd as mm
+from multimodal_sentiment_aanalysis_amd import _lib
 from multimodal_sentiment_aanalysis_amd.engine import BertTextNet, ResNetImageNet, materialize
 from oracle import fusion as OF
 from oracle import model as OM
@@ -132,6 +135,40 @@ def test_resnet_engine(dev, precision, pol, tol_f, tol_g, rcfg, B, HW):
     names = [n for n, _ in net.named_parameters()]
     ref_g = _oracle_grads({k: v.clone() for k, v in sd.items()}, names, lambda w: (feat_fn(w) * wgt).sum())
     _check_grads(_grads(net), ref_g, tol_g, f"resnet {precision}", l2=True)
+
+
+def test_resnet_strided_dgrad_parity_classes(dev, monkeypatch):
+    """The stride-2 3x3 data gradient as four parity-class GEMMs (resnet_engine.hip conv_dgrad) against the single row
+    gather over all pixels (MMSA_NO_PARITY_DGRAD=1): same forward, same bf16 rounding points, only the fp32 summation
+    order of a dx element differs, so every parameter gradient must agree to bf16 resolution."""
+    image, _, _, _ = synth_batch(4, 8, 96, 96, 10, seed=3)
+    wgt = torch.randn(4, 256, generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def run(no_parity):
+        if no_parity:
+            monkeypatch.setenv("MMSA_NO_PARITY_DGRAD", "1")
+        else:
+            monkeypatch.delenv("MMSA_NO_PARITY_DGRAD", raising=False)
+        torch.manual_seed(0)
+        net = ResNetImageNet(MINI_RESNET)
+        net.precision = "bf16"
+        net.to(dev)
+        net.train()
+        out = net(image.to(dev))
+        L = _lib.load()
+        L.mmsa_prof_mode(0)
+        L.mmsa_prof_begin(4096)
+        (out * wgt).sum().backward()
+        torch.cuda.synchronize()
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        L.mmsa_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+        return out.detach().cpu(), _grads(net), n.value
+
+    out_a, ga, na = run(False)
+    out_b, gb, nb = run(True)
+    assert torch.equal(out_a, out_b)
+    assert na == nb + 9, f"three strided 3x3 convolutions x (4 class GEMMs instead of 1): {na} vs {nb} MFMA launches"
+    _check_grads(ga, gb, 2e-2, "parity-class dgrad vs row gather", l2=True)
 
 
 def test_resnet_eval_mode(dev):

@@ -2,6 +2,7 @@
 the planner's choice and time against every forced tile shape. usage: sweep_report.py <tag> [min_gain_us]"""
 import csv, sys, collections
 tag = sys.argv[1]; thr = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+STEPS = 3  # bench.py dumps 3 stamped steps
 cfgs = ["auto", "4", "3", "2", "2_2", "2_1"]
 rows = {c: list(csv.DictReader(open(f"gpurun_out/{tag}_sweep_{c}.csv"))) for c in cfgs}
 n = len(rows["auto"])
@@ -18,9 +19,9 @@ tot_auto = tot_best = 0.0
 print(f"{'M,N,K,akm,bkm,gather,epi':46s} cnt  auto(plan)            " + " ".join(f"{c:>8s}" for c in cfgs[1:]) + "   gain/step")
 for key, e in agg.items():
     best = min(cfgs, key=lambda c: e[c])
-    gain = e["auto"] - e[best]
-    tot_auto += e["auto"]; tot_best += e[best]
+    gain = (e["auto"] - e[best]) / STEPS
+    tot_auto += e["auto"] / STEPS; tot_best += e[best] / STEPS
     if gain >= thr:
-        print(f"{','.join(key):46s} {e['cnt']:3d} {e['auto']/e['cnt']:7.1f} {e['plan']:12s} " +
+        print(f"{','.join(key):46s} {e['cnt']//STEPS:3d} {e['auto']/e['cnt']:7.1f} {e['plan']:12s} " +
               " ".join(f"{e[c]/e['cnt']:8.1f}" for c in cfgs[1:]) + f"   {gain:7.1f} -> {best} {e[best+'_plan']}")
 print(f"total auto {tot_auto/1e3:.3f} ms/step, per-signature best {tot_best/1e3:.3f} ms/step")
