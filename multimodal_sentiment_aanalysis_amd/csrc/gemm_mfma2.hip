@@ -837,11 +837,25 @@ static inline int g2_bn(const G2Plan& pl) { return pl.nj * 16 * (8 / pl.wm); }
 // Tile shape and K split. Cost model in microseconds, calibrated on MI355X (profiles/): a K step of the 256-row tile
 // costs about the same for every width (the 32 KiB A tile, the barrier and the LDS traffic dominate; MFMA-only time is
 // 0.19 us per 32 columns): t_step = 1.0 + 0.06 nj; per item 0.3 + 0.2 nj (pipeline bubble + epilogue stores);
-// the 128-row tile moves 2/3 of the bytes and half of the MFMAs per step: t_step = 0.42 + 0.07 per 32 columns
-// (in situ: 3136x512x2048 at 128x128 0.70 us / step, at 128x64 0.56);
+// the 128-row tile moves 2/3 of the bytes and half of the MFMAs per step: t_step = 0.72 + 0.05 per 32 columns (stand-
+// alone it measures 0.42 + 0.07, but planning with that costs the whole step 0.22 ms: A/B on one box, 20.27 vs 20.50);
 // a split adds the slab round trip at ~4 TB/s and the reducer launch. So: the biggest tile that keeps whole rounds of
 // `cus` workgroups busy, and as many K slices as it takes to fill the chip when there are few tiles (weight
 // gradients: 1..72 tiles with K = 8192..802816).
+// cost-model constants (microseconds); MMSA_G2_MODEL="a4,b4,a2,b2,c_split,d_split" overrides them for calibration runs
+struct G2Model { double a4, b4, a2, b2, c_split, d_split; };
+static const G2Model& g2_model() {
+  static const G2Model m = [] {
+    G2Model d{1.0, 0.06, 0.72, 0.05, 3.0, 2.0};
+    if (const char* v = getenv("MMSA_G2_MODEL")) {
+      G2Model t = d;
+      if (sscanf(v, "%lf,%lf,%lf,%lf,%lf,%lf", &t.a4, &t.b4, &t.a2, &t.b2, &t.c_split, &t.d_split) == 6) d = t;
+    }
+    return d;
+  }();
+  return m;
+}
+
 static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail, int force_wm = 0, int force_nj = 0) {
   const int nsteps = p.K / G2_BK;
   G2Plan best{4, 4, 1};
@@ -849,6 +863,7 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
   static const int cfgs[5][2] = {{4, 4}, {4, 3}, {4, 2}, {2, 2}, {2, 1}};
   // epilogue class: 0 plain store, 1 bias / activation / side output (registers only), 2 reads gelu' / residual operands
   const int epi = g2_epi_class(p);
+  const G2Model& mdl = g2_model();
   for (int ci = 0; ci < 5; ++ci) {
     const G2Plan shape{cfgs[ci][0], cfgs[ci][1], 1};
     if (force_wm && (shape.wm != force_wm || shape.nj != force_nj)) continue;
@@ -872,7 +887,7 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
         if (d > 1 && d <= smax && nc < 16) cand[nc++] = (int)d;
     }
     const int w32 = bn / 32;  // tile width in 32-column units
-    const double t_step = shape.wm == 4 ? 1.0 + 0.06 * w32 : 0.42 + 0.07 * w32;
+    const double t_step = shape.wm == 4 ? mdl.a4 + mdl.b4 * w32 : mdl.a2 + mdl.b2 * w32;
     const double t_item = shape.wm == 4 ? 0.3 + 0.2 * w32 : 0.3 + 0.1 * w32;
     // the register-only epilogue costs ~1 us per item, the one with side operands one memory round trip more; on the
     // 256x128 tile both run out of registers (accumulators + side operands + the loop's prefetched fragments: the
@@ -887,7 +902,7 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
       const long rounds = (items + cus - 1) / cus;
       // (with a K split the tiles store raw slabs and the reducer applies the epilogue)
       double cost = (double)rounds * (per * t_step + t_item + (split == 1 && !no_epi ? epi_cost[epi][ci] : 0.0)) + 1e-3 * waste;
-      if (split > 1) cost += 3.0 + 2.0 * split * (double)p.M * p.N * 4.0 / 4e6;
+      if (split > 1) cost += mdl.c_split + mdl.d_split * split * (double)p.M * p.N * 4.0 / 4e6;
       if (cost < best_cost - 1e-9) { best_cost = cost; best = G2Plan{shape.wm, shape.nj, split}; }
     }
   }
