@@ -141,7 +141,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ res,
-                                                       T* __restrict__ y, int M, int C, int cthreads, int act) {
+                                                       T* __restrict__ y, int M, int C, int cthreads, int act,
+                                                       unsigned char* __restrict__ mask) {
   const int ct = threadIdx.x % cthreads, rl = threadIdx.x / cthreads, rlanes = 256 / cthreads;
   const int col = (blockIdx.y * cthreads + ct) * 8;
   if (col >= C) return;
@@ -155,6 +156,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v.lo[e] = apply_act(v.lo[e], act); v.hi[e] = apply_act(v.hi[e], act); }
     Vec8<T>::store(y + r * C + col, v);
+    if (mask) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bits |= (v.lo[e] > 0.f ? 1u << e : 0u) | (v.hi[e] > 0.f ? 16u << e : 0u);
+      mask[(r * C + col) >> 3] = (unsigned char)bits;
+    }
   };
   for (long r = (long)blockIdx.x * rlanes + rl; r < M; r += stride) {
     const f32x8 x0 = Vec8<T>::load(x + r * C + col);
@@ -182,13 +189,21 @@ __device__ __forceinline__ f32x8 bn_dz(f32x8 dy, f32x8 xh, f32x8 g, f32x8 b, f32
   return f32x8{bn_dz4(dy.lo, xh.lo, g.lo, b.lo, yv.lo, act), bn_dz4(dy.hi, xh.hi, g.hi, b.hi, yv.hi, act)};
 }
 
+__device__ __forceinline__ f32x8 mask8(unsigned bits) {  // the saved ReLU mask as a stand-in for the output's sign
+  f32x8 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v.lo[e] = (bits >> e) & 1u ? 1.f : 0.f; v.hi[e] = (bits >> (4 + e)) & 1u ? 1.f : 0.f; }
+  return v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                              const T* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ part, int M, int C, int cthreads,
-                                                             int rows_per_chunk, int act) {
+                                                             int rows_per_chunk, int act,
+                                                             const unsigned char* __restrict__ mask) {
   __shared__ f32x4 red[4][256];
   const int ct = threadIdx.x % cthreads, rl = threadIdx.x / cthreads, rlanes = 256 / cthreads;
   const int col = (blockIdx.y * cthreads + ct) * 8;
@@ -198,10 +213,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
     const f32x8 mu = ld8(mean + col), is = ld8(invstd + col);
     const f32x8 g = ld8(gamma + col), b = ld8(beta + col);
     const f32x8 sc = is * g, sh = b - mu * sc;  // as bn_apply_kernel: the ReLU mask without a saved output (y == null)
-    const bool rd_y = act == MMSA_ACT_RELU && y;
+    const bool rd_y = act == MMSA_ACT_RELU && y && !mask;
+    const bool rd_m = act == MMSA_ACT_RELU && mask;
     auto one = [&](f32x8 xr, f32x8 dv, f32x8 yv) {
       const f32x8 xh = (xr - mu) * is;
-      if (act == MMSA_ACT_RELU && !y) yv = xr * sc + sh;
+      if (act == MMSA_ACT_RELU && !y && !mask) yv = xr * sc + sh;
       const f32x8 dz = bn_dz(dv, xh, g, b, yv, act);
       s = s + dz;
       q = q + dz * xh;
@@ -213,6 +229,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
       const f32x8 d0 = Vec8<T>::load(dy + o0), d1 = Vec8<T>::load(dy + o1);
       f32x8 y0 = zero8(), y1 = zero8();
       if (rd_y) { y0 = Vec8<T>::load(y + o0); y1 = Vec8<T>::load(y + o1); }
+      if (rd_m) { y0 = mask8(mask[o0 >> 3]); y1 = mask8(mask[o1 >> 3]); }
       one(x0, d0, y0);
       one(x1, d1, y1);
     }
@@ -220,6 +237,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
       const long o0 = (long)r * C + col;
       f32x8 y0 = zero8();
       if (rd_y) y0 = Vec8<T>::load(y + o0);
+      if (rd_m) y0 = mask8(mask[o0 >> 3]);
       one(Vec8<T>::load(x + o0), Vec8<T>::load(dy + o0), y0);
     }
   }
@@ -275,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ sums, T* __restrict__ dx,
                                                            T* __restrict__ dres, int M, int C, int cthreads, int act,
-                                                           int training) {
+                                                           int training, const unsigned char* __restrict__ mask) {
   const int ct = threadIdx.x % cthreads, rl = threadIdx.x / cthreads, rlanes = 256 / cthreads;
   const int col = (blockIdx.y * cthreads + ct) * 8;
   if (col >= C) return;
@@ -289,11 +307,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
   const f32x8 gi = g * is;
   const f32x8 sc = is * g, sh = b - mu * sc;
-  const bool rd_y = act == MMSA_ACT_RELU && y;
+  const bool rd_y = act == MMSA_ACT_RELU && y && !mask;
+  const bool rd_m = act == MMSA_ACT_RELU && mask;
   const long stride = (long)gridDim.x * rlanes;
   auto one = [&](long r, f32x8 xr, f32x8 dv, f32x8 yv) {
     const f32x8 xh = (xr - mu) * is;
-    if (act == MMSA_ACT_RELU && !y) yv = xr * sc + sh;
+    if (act == MMSA_ACT_RELU && !y && !mask) yv = xr * sc + sh;
     const f32x8 dz = bn_dz(dv, xh, g, b, yv, act);
     if (dres) Vec8<T>::store(dres + r * C + col, dz);
     Vec8<T>::store(dx + r * C + col, gi * (dz - mb - xh * mg));
@@ -302,6 +321,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const long o0 = r * C + col;
     f32x8 y0 = zero8();
     if (rd_y) y0 = Vec8<T>::load(y + o0);
+    if (rd_m) y0 = mask8(mask[o0 >> 3]);
     one(r, Vec8<T>::load(x + o0), Vec8<T>::load(dy + o0), y0);
   }
 }
@@ -311,7 +331,7 @@ size_t bn_ws_bytes(int C) { return ((size_t)BN_CHUNKS * 2 * C + 2 * C) * sizeof(
 template <typename T>
 static int bn_forward_t(const T* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                         float* mean, float* invstd, const T* res, T* y, float* ws, int M, int C, float eps, float momentum,
-                        int act, int training, hipStream_t st) {
+                        int act, int training, hipStream_t st, unsigned char* mask) {
   const BnMap m = bn_map(C);
   if (training) {
     const int rpc = max(cdiv(M, BN_CHUNKS), m.rlanes * 16);
@@ -325,49 +345,51 @@ static int bn_forward_t(const T* x, const float* gamma, const float* beta, float
   }
   const int gx = (int)min((long)cdiv(M, m.rlanes), 4096L);
   hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(gx, m.cgroups), dim3(256), 0, st, x, (const float*)mean,
-                     (const float*)invstd, gamma, beta, res, y, M, C, m.cthreads, act);
+                     (const float*)invstd, gamma, beta, res, y, M, C, m.cthreads, act, mask);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
 
 int bn_forward(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                float* mean, float* invstd, const void* res, void* y, float* ws, int M, int C, float eps, float momentum,
-               int act, int training, hipStream_t st) {
+               int act, int training, hipStream_t st, unsigned char* relu_mask) {
   if (C % 8 || M <= 0) return MMSA_ERR_ARG;
   if (!training && (!running_mean || !running_var)) return MMSA_ERR_ARG;
+  if (relu_mask && act != MMSA_ACT_RELU) return MMSA_ERR_ARG;
   if (dtype == MMSA_BF16)
     return bn_forward_t<bf16>((const bf16*)x, gamma, beta, running_mean, running_var, mean, invstd, (const bf16*)res,
-                              (bf16*)y, ws, M, C, eps, momentum, act, training, st);
+                              (bf16*)y, ws, M, C, eps, momentum, act, training, st, relu_mask);
   return bn_forward_t<float>((const float*)x, gamma, beta, running_mean, running_var, mean, invstd, (const float*)res,
-                             (float*)y, ws, M, C, eps, momentum, act, training, st);
+                             (float*)y, ws, M, C, eps, momentum, act, training, st, relu_mask);
 }
 
 template <typename T>
 static int bn_backward_t(const T* dy, const T* x, const T* y, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, T* dx, T* dres, float* dgamma, float* dbeta, int accumulate, float* ws, int M,
-                         int C, int act, int training, hipStream_t st) {
+                         int C, int act, int training, hipStream_t st, const unsigned char* mask) {
   const BnMap m = bn_map(C);
   const int rpc = max(cdiv(M, BN_CHUNKS), m.rlanes * 16);
   const int chunks = cdiv(M, rpc);
   float* sums = ws + (size_t)BN_CHUNKS * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(chunks, m.cgroups), dim3(256), 0, st, dy, x, y, mean, invstd, gamma,
-                     beta, ws, M, C, m.cthreads, rpc, act);
+                     beta, ws, M, C, m.cthreads, rpc, act, mask);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, BN_FIN_COLS)), dim3(256), 0, st, (const float*)ws, chunks, C, sums,
                      dgamma, dbeta, accumulate);
   const int gx = (int)min((long)cdiv(M, m.rlanes), 4096L);
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(gx, m.cgroups), dim3(256), 0, st, dy, x, y, mean, invstd, gamma, beta,
-                     (const float*)sums, dx, dres, M, C, m.cthreads, act, training);
+                     (const float*)sums, dx, dres, M, C, m.cthreads, act, training, mask);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
 
 int bn_backward(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
                 const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
-                float* ws, int M, int C, int act, int training, hipStream_t st) {
+                float* ws, int M, int C, int act, int training, hipStream_t st, const unsigned char* relu_mask) {
   if (C % 8 || M <= 0) return MMSA_ERR_ARG;
+  if (relu_mask && act != MMSA_ACT_RELU) return MMSA_ERR_ARG;
   if (dtype == MMSA_BF16)
     return bn_backward_t<bf16>((const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, gamma, beta, (bf16*)dx,
-                               (bf16*)dres, dgamma, dbeta, accumulate, ws, M, C, act, training, st);
+                               (bf16*)dres, dgamma, dbeta, accumulate, ws, M, C, act, training, st, relu_mask);
   return bn_backward_t<float>((const float*)dy, (const float*)x, (const float*)y, mean, invstd, gamma, beta, (float*)dx,
-                              (float*)dres, dgamma, dbeta, accumulate, ws, M, C, act, training, st);
+                              (float*)dres, dgamma, dbeta, accumulate, ws, M, C, act, training, st, relu_mask);
 }

@@ -34,10 +34,12 @@ int tanh_bwd(int dtype, const void* dy, const void* y, void* dx, long n, hipStre
 size_t bn_ws_bytes(int C);
 int bn_forward(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                float* mean, float* invstd, const void* res, void* y, float* ws, int M, int C, float eps, float momentum,
-               int act, int training, hipStream_t st);
+               int act, int training, hipStream_t st, unsigned char* relu_mask = nullptr);
 int bn_backward(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
                 const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
-                float* ws, int M, int C, int act, int training, hipStream_t st);
+                float* ws, int M, int C, int act, int training, hipStream_t st, const unsigned char* relu_mask = nullptr);
+// relu_mask (optional, act == RELU): [M][C/8] bytes, bit e of byte (m, c/8) = output (m, c+e) > 0. Written by the forward,
+// read by the backward instead of the saved output y (1/16 of its bytes in two streamed passes).
 
 // poolops.hip
 int stem_im2col(int dtype, const float* img, void* col, int B, int Cin, int H, int W, int OH, int OW, int KH, int KW,

@@ -81,6 +81,7 @@ static bool res_cfg_ok(const mmsa_resnet_cfg& c) {
 struct ConvWs {
   void *z, *y;  // conv output (pre-BN), BN(+act) output
   float *mean, *invstd;
+  unsigned char* mask;  // bn3 only: sign bits of the block output relu(bn3 + identity), [M][C/8] (bnops.hip)
 };
 struct BlockWs {
   ConvWs c1, c2, c3, ds;  // c3.y is the block output relu(bn3 + identity); ds.y the projected identity
@@ -98,11 +99,12 @@ struct ResWs {
   size_t total;
 };
 
-static ConvWs conv_ws(Bump& b, const ConvDef& c, int B, size_t es, bool need_y = true) {
+static ConvWs conv_ws(Bump& b, const ConvDef& c, int B, size_t es, bool need_y = true, bool need_mask = false) {
   ConvWs w;
   const size_t n = (size_t)B * c.Hout * c.Wout * c.Cout;
   w.z = b.take(n * es);
   w.y = need_y ? b.take(n * es) : nullptr;
+  w.mask = need_mask ? (unsigned char*)b.take(n / 8) : nullptr;
   w.mean = (float*)b.take((size_t)c.Cout * 4);
   w.invstd = (float*)b.take((size_t)c.Cout * 4);
   return w;
@@ -128,7 +130,7 @@ static ResWs res_ws(const mmsa_resnet_cfg& c, const ResLayout& L, void* base) {
     BlockWs x;
     x.c1 = conv_ws(b, bd.c1, B, es);
     x.c2 = conv_ws(b, bd.c2, B, es);
-    x.c3 = conv_ws(b, bd.c3, B, es);
+    x.c3 = conv_ws(b, bd.c3, B, es, true, true);
     if (bd.has_ds) x.ds = conv_ws(b, bd.ds, B, es);
     w.blocks.push_back(x);
     const size_t a_in = (size_t)B * bd.c1.Hin * bd.c1.Win * (bd.c1.Cin > bd.c1.Cout ? bd.c1.Cin : bd.c1.Cout);
@@ -278,16 +280,21 @@ static int conv_wgrad(const ResCtx& r, const ConvDef& c, const void* dz, const v
   return r.e.gemm(p);
 }
 
+// the ReLU sign bits of a block output (MMSA_NO_BN_MASK=1: the backward reads the saved output instead; A/B hook)
+static unsigned char* bn_mask(const ConvWs& w, int act) {
+  static const bool off = [] { const char* v = getenv("MMSA_NO_BN_MASK"); return v && atoi(v) != 0; }();
+  return (off || act != MMSA_ACT_RELU) ? nullptr : w.mask;
+}
 static int bn_fwd(const ResCtx& r, const ConvDef& c, const ConvWs& w, const void* res, void* y, int act, float* bnws) {
   const int M = r.c.batch * c.Hout * c.Wout;
   return bn_forward(r.c.dtype, w.z, r.P(c.g), r.P(c.b), r.bnbuf + c.rm, r.bnbuf + c.rv, w.mean, w.invstd, res, y, bnws, M,
-                    c.Cout, r.c.bn_eps, r.c.bn_momentum, act, r.c.training, r.e.st);
+                    c.Cout, r.c.bn_eps, r.c.bn_momentum, act, r.c.training, r.e.st, bn_mask(w, act));
 }
 static int bn_bwd(const ResCtx& r, const ConvDef& c, const ConvWs& w, const void* dy, const void* y, void* dz, void* dres,
                   int act, float* bnws) {
   const int M = r.c.batch * c.Hout * c.Wout;
   return bn_backward(r.c.dtype, dy, w.z, y, w.mean, w.invstd, r.P(c.g), r.P(c.b), dz, dres, r.G(c.g), r.G(c.b), r.acc, bnws,
-                     M, c.Cout, act, r.c.training, r.e.st);
+                     M, c.Cout, act, r.c.training, r.e.st, bn_mask(w, act));
 }
 
 extern "C" {
