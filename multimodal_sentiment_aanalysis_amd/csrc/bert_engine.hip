@@ -74,6 +74,8 @@ struct BertWs {
   std::vector<BertLayerWs> L;
   void *pooled, *dfeat_t, *dpool, *dprepool;
   void *bufA, *bufB, *bufC, *bufD, *bufI, *bufQ;
+  void* ones8;  // [B*S][8] bf16 ones (grouped bias gradients, engine_common.h)
+  size_t colws_bytes;
   float *splitk, *colws, *lnws, *attnws;
   size_t splitk_bytes;
   size_t total;
@@ -119,6 +121,8 @@ static BertWs bert_ws(const mmsa_bert_cfg& c, void* base) {
   w.splitk = (float*)b.take(w.splitk_bytes);
   size_t colb = colsum_ws_bytes((int)(3 * H > I ? 3 * H : I));
   w.colws = (float*)b.take(colb);
+  w.colws_bytes = colb;
+  w.ones8 = b.take(M * 8 * 2);
   w.lnws = (float*)b.take(layernorm_bwd_ws_bytes((int)H));
   w.attnws = (float*)b.take(attention_bwd_ws_bytes(c.batch, c.seq, c.heads));
   w.total = b.off;
@@ -201,6 +205,11 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
   Eng e{c.dtype, st, ws.splitk, ws.splitk_bytes, ws.colws};
   const size_t es = e.esz();
   const int M = c.batch * c.seq, H = c.hidden, I = c.intermediate, S = c.seq, B = c.batch, D = c.out_dim;
+  if (c.dtype == MMSA_BF16) {  // bias gradients ride in the grouped weight-gradient launch (Eng::wgrad_group)
+    RET_IF(fill_ones_bf16(ws.ones8, (long)M * 8, st));
+    e.ones8 = ws.ones8;
+    e.col_ws_bytes = ws.colws_bytes;
+  }
   const int aimpl = e.attn_impl();
   const int acc = accumulate ? 1 : 0;
   auto W = [&](long off) { return (const void*)at(wt, off, es); };

@@ -53,9 +53,9 @@ int mmsa_gemm(const mmsa_gemm_desc* d, int32_t impl, void* stream) {
 }
 
 int mmsa_gemm_group(const mmsa_gemm_desc* d, int32_t n, void* stream) {
-  if (!d || n < 1 || n > 4) return MMSA_ERR_ARG;
-  GemmParams ps[4];
-  float* cs[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (!d || n < 1 || n > 6) return MMSA_ERR_ARG;
+  GemmParams ps[6];
+  float* cs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   for (int g = 0; g < n; ++g) {
     if (!d[g].A || !d[g].B || !d[g].C) return MMSA_ERR_ARG;
     ps[g] = to_params(&d[g]);

@@ -61,6 +61,8 @@ struct Eng {
   float* splitk_ws;
   size_t splitk_bytes;
   float* col_ws;  // colsum partials
+  size_t col_ws_bytes = 0;      // capacity of col_ws (0: unknown, bias problems are not grouped)
+  const void* ones8 = nullptr;  // optional [rows][8] bf16 ones (rows >= the M of wgrad_group): bias gradients ride in the group
 
   size_t esz() const { return dtype == MMSA_BF16 ? 2 : 4; }
   // MMSA_BF16_SIMT=1 (diagnostic): run the bf16 path on the SIMT kernels — same storage rounding, independent code —
@@ -164,8 +166,22 @@ struct Eng {
   struct WgradJob { const void* dy; long lddy; const void* x; long ldx; float* dW; float* db; int N, K; };
   int wgrad_group(const WgradJob* jobs, int n, int M, int accumulate) const {
     if (dtype == MMSA_BF16 && !force_simt() && !accumulate && n >= 2 && n <= 4) {
-      GemmParams ps[4];
-      float* cs[4];
+      GemmParams ps[6];
+      float* cs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      // Bias gradients db_g[n] = sum_m dy_g[m][n] as extra problems of the same launch: dy_g^T x ones[M][8] -> [N_g][8]
+      // fp32 in col_ws (every column holds db_g), picked up by one small kernel. The group's weight-gradient tiles do
+      // not fill the chip (BERT-base layer: 216 tiles of 256x128 on 256 CUs), so the 9-12 extra tiles of a bias problem
+      // run on CUs that were idle anyway — instead of a column-sum kernel + its finalize per bias (4 launches a layer).
+      static const bool no_bias_group = [] { const char* v = getenv("MMSA_NO_BIAS_GROUP"); return v && atoi(v) != 0; }();
+      int nb = 0, bias_of[2] = {-1, -1};
+      long scratch_off[2] = {0, 0};
+      if (ones8 && !no_bias_group) {
+        long off = 0;
+        for (int g = 0; g < n && nb < 2; ++g)
+          if (jobs[g].db && (size_t)(off + (long)jobs[g].N * 8) * sizeof(float) <= col_ws_bytes) {
+            bias_of[nb] = g; scratch_off[nb] = off; off += (long)jobs[g].N * 8; ++nb;
+          }
+      }
       for (int g = 0; g < n; ++g) {
         GemmParams p = blank();
         p.A = jobs[g].dy; p.lda = jobs[g].lddy; p.a_kmajor = 1; p.B = jobs[g].x; p.ldb = jobs[g].ldx; p.b_kmajor = 1;
@@ -174,11 +190,26 @@ struct Eng {
         cs[g] = nullptr;  // (the kernel can fuse the column sums — G2_GROUP_COLSUM — but the extra accumulators make the
                           //  256x128 variant spill inside its main loop; the bias gradients stay separate launches)
       }
-      const int rc = gemm_bf16_launch_group(ps, cs, n, st);
+      for (int b = 0; b < nb; ++b) {
+        const WgradJob& j = jobs[bias_of[b]];
+        GemmParams p = blank();
+        p.A = j.dy; p.lda = j.lddy; p.a_kmajor = 1; p.B = ones8; p.ldb = 8; p.b_kmajor = 1;
+        p.C = col_ws + scratch_off[b]; p.ldc = 8; p.M = j.N; p.N = 8; p.K = M; p.out_f32 = 1;
+        ps[n + b] = p;
+      }
+      int rc = gemm_bf16_launch_group(ps, cs, n + nb, st);
+      bool biases_in_group = rc != MMSA_ERR_UNSUPPORTED && nb > 0;
+      if (rc == MMSA_ERR_UNSUPPORTED && nb > 0) rc = gemm_bf16_launch_group(ps, cs, n, st);  // without the bias problems
       if (rc != MMSA_ERR_UNSUPPORTED) {
         if (rc) return rc;
-        for (int g = 0; g < n; ++g)
-          if (jobs[g].db) RET_IF(bias_grad(jobs[g].dy, jobs[g].lddy, jobs[g].db, M, jobs[g].N, accumulate));
+        if (biases_in_group)
+          RET_IF(bias_pick(col_ws + scratch_off[0], jobs[bias_of[0]].db, jobs[bias_of[0]].N,
+                           nb > 1 ? col_ws + scratch_off[1] : nullptr, nb > 1 ? jobs[bias_of[1]].db : nullptr,
+                           nb > 1 ? jobs[bias_of[1]].N : 0, st));
+        for (int g = 0; g < n; ++g) {
+          const bool done = biases_in_group && (g == bias_of[0] || g == bias_of[1]);
+          if (jobs[g].db && !done) RET_IF(bias_grad(jobs[g].dy, jobs[g].lddy, jobs[g].db, M, jobs[g].N, accumulate));
+        }
         return MMSA_OK;
       }
     }

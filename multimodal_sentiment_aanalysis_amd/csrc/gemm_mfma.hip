@@ -505,7 +505,8 @@ int gemm_bf16_launch_group(const GemmParams* probs, float* const* colsum, int n,
   for (int g = 0; g < n; ++g) r.flop += 2.0 * probs[g].M * probs[g].N * (double)probs[g].K;
   r.M = -n; r.N = 0; r.K = probs[0].K; r.akm = 1; r.bkm = 1; r.gather = 0; r.split = 1; r.epi = 0;
   if (g_prof_mode == 1) {
-    GemmParams ps[4];
+    GemmParams ps[8];
+    if (n > 8) return MMSA_ERR_UNSUPPORTED;
     for (int g = 0; g < n; ++g) ps[g] = probs[g];
     ps[0].stamp = g_stamp_dev + 2 * g_prof_used;
     const int rc = gemm2_launch_group(ps, colsum, n, st);

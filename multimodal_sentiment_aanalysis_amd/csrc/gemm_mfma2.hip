@@ -37,6 +37,7 @@
 #define G2_GROUP_COLSUM 0
 #endif
 
+#define G2_MAX_GROUPS 6
 struct G2Sched {
   int ntm, ntn, ntiles;  // tile grid
   int split_k, per;      // K splits; K steps per split
@@ -55,7 +56,7 @@ struct G2Sched {
     int M, N; long lda, ldb, ldc;
     int tile_begin, ntn;
     unsigned a_bytes, b_bytes, c_bytes;
-  } grp[4];
+  } grp[G2_MAX_GROUPS];
   unsigned long long* stamp;  // in-kernel timing record or null
   int dbg;               // timing-only ablations (MMSA_G2_DBG bitmask; results are wrong): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no epilogue
 };
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       if (s.ngroups > 0) {
         int g = 0;
 #pragma unroll
-        for (int q = 1; q < 4; ++q)
+        for (int q = 1; q < G2_MAX_GROUPS; ++q)
           if (q < s.ngroups && item >= s.grp[q].tile_begin) g = q;
         const int tile = item - s.grp[g].tile_begin;
         const int tm = tile / s.grp[g].ntn, tn = tile - tm * s.grp[g].ntn;
@@ -1043,12 +1044,12 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   return MMSA_OK;
 }
 
-// Grouped launch: n (2..4) independent weight-gradient problems C_g[M_g, N_g] = A_g^T B_g with the same K, both operands
+// Grouped launch: n (2..6) independent weight-gradient problems C_g[M_g, N_g] = A_g^T B_g with the same K, both operands
 // k-major, fp32 output (overwrite), no K split: one persistent launch walks the tiles of all problems. colsum[g]
 // (optional) receives sum_k A_g[k][m] = the bias gradient of that Linear. Returns MMSA_ERR_UNSUPPORTED when the
 // problems do not fit (the caller then launches them one by one).
 int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st) {
-  if (n < 1 || n > 4) return MMSA_ERR_UNSUPPORTED;
+  if (n < 1 || n > G2_MAX_GROUPS) return MMSA_ERR_UNSUPPORTED;
   const int K = probs[0].K;
   for (int g = 0; g < n; ++g) {
     const GemmParams& q = probs[g];

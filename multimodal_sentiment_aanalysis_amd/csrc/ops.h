@@ -30,6 +30,10 @@ int attention_bwd(int impl, const void* qkv, const float* mask, const void* dctx
                   int heads, int head_dim, hipStream_t st);
 int tanh_bwd(int dtype, const void* dy, const void* y, void* dx, long n, hipStream_t st);
 
+// dst[i] = src[8 i] for one or two (src, dst, n) pairs: picks the bias gradients out of the grouped launch's [N][8] results
+int bias_pick(const float* src, float* dst, int n, const float* src2, float* dst2, int n2, hipStream_t st);
+int fill_ones_bf16(void* dst, long n, hipStream_t st);
+
 // bnops.hip
 size_t bn_ws_bytes(int C);
 int bn_forward(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,

@@ -467,3 +467,21 @@ int tanh_bwd(int dtype, const void* dy, const void* y, void* dx, long n, hipStre
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ grouped bias gradients
+__global__ __launch_bounds__(256) void bias_pick_kernel(const float* __restrict__ src, float* __restrict__ dst, int n,
+                                                        const float* __restrict__ src2, float* __restrict__ dst2, int n2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[(long)i * 8];
+  else if (i - n < n2) dst2[i - n] = src2[(long)(i - n) * 8];
+}
+int bias_pick(const float* src, float* dst, int n, const float* src2, float* dst2, int n2, hipStream_t st) {
+  if (n <= 0 || n2 < 0) return MMSA_ERR_ARG;
+  hipLaunchKernelGGL(bias_pick_kernel, dim3(cdiv(n + n2, 256)), dim3(256), 0, st, src, dst, n, src2, dst2, n2);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+int fill_ones_bf16(void* dst, long n, hipStream_t st) {
+  if (hipMemsetD16Async((hipDeviceptr_t)dst, 0x3F80, (size_t)n, st) != hipSuccess) return MMSA_ERR_LAUNCH;  // bf16 1.0
+  return MMSA_OK;
+}
