@@ -83,31 +83,36 @@ __global__ __launch_bounds__(256) void gemm_simt_kernel(GemmParams p) {
   // dimension (the fusion head's Linears: 57 launches per step, each a short serial K loop)
   const bool vec = std::is_same<T, float>::value && p.gather == 0 && !(p.lda & 3) && !(p.ldb & 3) && !(p.K & 3) &&
                    !(p.M & 3) && !(p.N & 3) && !(((size_t)p.A | (size_t)p.B) & 15);
+  // fp32 fast path: register double buffering — the global loads of step k+1 are in flight while step k is computed
+  // (the head's split launches walk 2 steps per block: their two HBM round trips used to run back to back)
+  f32x4 va[2], vb[2];
+  auto vec_load = [&](int k0) __attribute__((always_inline)) {
+    const float* A = (const float*)p.A;
+    const float* B = (const float*)p.B;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // 64 x 32 elements = 512 float4 per operand, 2 per thread
+      const int e = tid + 256 * i;
+      va[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      vb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.a_kmajor) {  // [K][M]: 16 float4 per k-row
+        const int kk = e >> 4, mm = (e & 15) * 4;
+        if (k0 + kk < kend && m0 + mm < p.M) va[i] = *(const f32x4*)(A + (long)(k0 + kk) * p.lda + m0 + mm);
+      } else {           // [M][K]: 8 float4 per row
+        const int mm = e >> 3, kk = (e & 7) * 4;
+        if (k0 + kk < kend && m0 + mm < p.M) va[i] = *(const f32x4*)(A + (long)(m0 + mm) * p.lda + k0 + kk);
+      }
+      if (p.b_kmajor) {
+        const int kk = e >> 4, nn = (e & 15) * 4;
+        if (k0 + kk < kend && n0 + nn < p.N) vb[i] = *(const f32x4*)(B + (long)(k0 + kk) * p.ldb + n0 + nn);
+      } else {
+        const int nn = e >> 3, kk = (e & 7) * 4;
+        if (k0 + kk < kend && n0 + nn < p.N) vb[i] = *(const f32x4*)(B + (long)(n0 + nn) * p.ldb + k0 + kk);
+      }
+    }
+  };
+  if (vec && kbeg < kend) vec_load(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += SBK) {
     if (vec) {
-      const float* A = (const float*)p.A;
-      const float* B = (const float*)p.B;
-      f32x4 va[2], vb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {  // 64 x 32 elements = 512 float4 per operand, 2 per thread
-        const int e = tid + 256 * i;
-        va[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        vb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.a_kmajor) {  // [K][M]: 16 float4 per k-row
-          const int kk = e >> 4, mm = (e & 15) * 4;
-          if (k0 + kk < kend && m0 + mm < p.M) va[i] = *(const f32x4*)(A + (long)(k0 + kk) * p.lda + m0 + mm);
-        } else {           // [M][K]: 8 float4 per row
-          const int mm = e >> 3, kk = (e & 7) * 4;
-          if (k0 + kk < kend && m0 + mm < p.M) va[i] = *(const f32x4*)(A + (long)(m0 + mm) * p.lda + k0 + kk);
-        }
-        if (p.b_kmajor) {
-          const int kk = e >> 4, nn = (e & 15) * 4;
-          if (k0 + kk < kend && n0 + nn < p.N) vb[i] = *(const f32x4*)(B + (long)(k0 + kk) * p.ldb + n0 + nn);
-        } else {
-          const int nn = e >> 3, kk = (e & 7) * 4;
-          if (k0 + kk < kend && n0 + nn < p.N) vb[i] = *(const f32x4*)(B + (long)(n0 + nn) * p.ldb + k0 + kk);
-        }
-      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int e = tid + 256 * i;
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256) void gemm_simt_kernel(GemmParams p) {
           for (int r = 0; r < 4; ++r) Bs[kk + r][nn] = vb[i][r];
         }
       }
+      if (k0 + SBK < kend) vec_load(k0 + SBK);  // prefetch: consumed after this step's compute
     } else {
 
     // 64x16 elements per operand, 4 per thread. Pick the thread->element map so global reads are coalesced

@@ -321,18 +321,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 #define COLSUM_CHUNKS 128
 size_t colsum_ws_bytes(int N) { return (size_t)COLSUM_CHUNKS * N * sizeof(float); }
 
-// small / unaligned widths (the 3-class logits): one thread per column, fixed order
+// small / unaligned widths (the 3-class logits) and short matrices: one thread per column, fixed order
 template <typename T>
 __global__ void colsum_small_kernel(const T* __restrict__ x, long ldx, float* __restrict__ out, int accumulate, int M, int N) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= N) return;
   float a = 0.f;
-  for (int r = 0; r < M; ++r) a += to_f32<T>(x[(long)r * ldx + c]);
+  int r = 0;
+  for (; r + 8 <= M; r += 8) {  // eight independent loads in flight, summed in row order
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = to_f32<T>(x[(long)(r + e) * ldx + c]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a += v[e];
+  }
+  for (; r < M; ++r) a += to_f32<T>(x[(long)r * ldx + c]);
   out[c] = accumulate ? out[c] + a : a;
 }
 
 int colsum(int dtype, const void* x, long ldx, float* out, int accumulate, float* ws, int M, int N, hipStream_t st) {
-  if (N % 4 || ldx % 4) {
+  // few rows (the fusion head: M = batch): one pass, one launch (the two-stage form costs a second launch for nothing)
+  if (N % 4 || ldx % 4 || M <= 128) {
     if (dtype == MMSA_BF16)
       hipLaunchKernelGGL(colsum_small_kernel<bf16>, dim3(cdiv(N, 64)), dim3(64), 0, st, (const bf16*)x, ldx, out, accumulate, M, N);
     else
