@@ -129,6 +129,12 @@ static BertWs bert_ws(const mmsa_bert_cfg& c, void* base) {
   return w;
 }
 
+// MMSA_NO_GELU_FACTOR=1: keep the pre-activation in a.pre and evaluate gelu' in the backward epilogue (A/B hook)
+static int gelu_factor() {
+  static const bool off = [] { const char* v = getenv("MMSA_NO_GELU_FACTOR"); return v && atoi(v) != 0; }();
+  return off ? 0 : 1;
+}
+
 static inline const char* at(const void* base, long off, size_t es) { return (const char*)base + (size_t)off * es; }
 
 extern "C" {
@@ -183,7 +189,8 @@ int mmsa_bert_fwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
     RET_IF(attention_fwd(aimpl, a.qkv, mask, a.ctx, c.batch, S, c.heads, 64, st));
     RET_IF(e.linear_fwd(a.ctx, H, W(f.wo), P(f.bo), a.s1, H, M, H, H, MMSA_ACT_NONE, nullptr, x, H));
     RET_IF(layernorm_fwd(c.dtype, a.s1, P(f.ln1w), P(f.ln1b), a.h1, a.mean1, a.rstd1, M, H, c.ln_eps, st));
-    RET_IF(e.linear_fwd(a.h1, H, W(f.w1), P(f.b1), a.act, I, M, I, H, MMSA_ACT_GELU, a.pre));
+    // a.pre receives gelu'(pre-activation): the factor the backward multiplies by (one exp / erf for both outputs)
+    RET_IF(e.linear_fwd(a.h1, H, W(f.w1), P(f.b1), a.act, I, M, I, H, MMSA_ACT_GELU, a.pre, nullptr, 0, 0, gelu_factor()));
     RET_IF(e.linear_fwd(a.act, I, W(f.w2), P(f.b2), a.s2, H, M, H, I, MMSA_ACT_NONE, nullptr, a.h1, H));
     RET_IF(layernorm_fwd(c.dtype, a.s2, P(f.ln2w), P(f.ln2b), a.out, a.mean2, a.rstd2, M, H, c.ln_eps, st));
     x = a.out;
@@ -238,7 +245,7 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
     RET_IF(layernorm_bwd(c.dtype, dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, G(f.ln2w), G(f.ln2b), acc, ws.lnws, M, H, st,
                          G(f.b2)));
     void* dpre = ws.bufI;
-    RET_IF(e.linear_dgrad(ds2, H, W(f.w2), dpre, I, M, H, I, a.pre, I));  // * gelu'(pre)
+    RET_IF(e.linear_dgrad(ds2, H, W(f.w2), dpre, I, M, H, I, a.pre, I, nullptr, 0, gelu_factor()));  // * gelu'(pre), stored by the forward
     void* dh1 = bC;
     RET_IF(e.linear_dgrad(dpre, I, W(f.w1), dh1, H, M, I, H, nullptr, 0, ds2, H));  // + residual branch
     void* ds1 = dOut;

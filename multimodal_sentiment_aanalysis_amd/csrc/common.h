@@ -68,6 +68,14 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + copysignf(erf_as(au, e), x));
   return cdf + x * 0.39894228040143267794f * e;
 }
+// gelu(x) and gelu'(x) from one exp / erf evaluation
+struct GeluPair { float y, dy; };
+__device__ __forceinline__ GeluPair gelu_erf_both(float x) {
+  const float au = fabsf(x) * 0.70710678118654752440f;
+  const float e = __expf(-au * au);
+  const float cdf = 0.5f * (1.0f + copysignf(erf_as(au, e), x));
+  return GeluPair{x * cdf, cdf + x * 0.39894228040143267794f * e};
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float apply_act(float v, int act) {

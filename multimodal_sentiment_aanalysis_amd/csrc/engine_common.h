@@ -111,11 +111,12 @@ struct Eng {
   // y[M,N] = act(x[M,K] W[N,K]^T + bias) (+ add)
   int linear_fwd(const void* x, long ldx, const void* W, const float* bias, void* y, long ldy, int M, int N, int K,
                  int act = MMSA_ACT_NONE, void* pre = nullptr, const void* add = nullptr, long ldadd = 0,
-                 int out_f32 = 0) const {
+                 int out_f32 = 0, int pre_is_gelu_grad = 0) const {
     GemmParams p = blank();
     p.A = x; p.lda = ldx; p.B = W; p.ldb = K; p.C = y; p.ldc = ldy;
     p.M = M; p.N = N; p.K = K;
     p.bias = bias; p.act = act; p.C2 = pre; p.ldc2 = N; p.add = add; p.ldadd = ldadd; p.out_f32 = out_f32;
+    p.c2_gelu_grad = (pre && act == MMSA_ACT_GELU) ? pre_is_gelu_grad : 0;
     small_split(p);
     return gemm(p);
   }
@@ -132,11 +133,12 @@ struct Eng {
   }
   // dx[M,K] = dy[M,N] W[N,K]  (* gelu'(mul)) (+ add)
   int linear_dgrad(const void* dy, long lddy, const void* W, void* dx, long lddx, int M, int N, int K,
-                   const void* mul = nullptr, long ldmul = 0, const void* add = nullptr, long ldadd = 0) const {
+                   const void* mul = nullptr, long ldmul = 0, const void* add = nullptr, long ldadd = 0,
+                   int mul_is_factor = 0) const {
     GemmParams p = blank();
     p.A = dy; p.lda = lddy; p.B = W; p.ldb = K; p.b_kmajor = 1; p.C = dx; p.ldc = lddx;
     p.M = M; p.N = K; p.K = N;
-    p.mul = mul; p.ldmul = ldmul; p.add = add; p.ldadd = ldadd;
+    p.mul = mul; p.ldmul = ldmul; p.add = add; p.ldadd = ldadd; p.mul_is_factor = mul ? mul_is_factor : 0;
     small_split(p);
     return gemm(p);
   }

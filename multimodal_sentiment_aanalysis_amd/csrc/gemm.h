@@ -55,6 +55,10 @@ struct GemmParams {
   long ldmul;
   const void* add;
   long ldadd;
+  // engine-internal variants of the two GELU operands (0 = the documented forms): c2_gelu_grad: C2 receives gelu'(v)
+  // instead of v (act must be GELU); mul_is_factor: `mul` already holds that factor (v *= mul, no gelu' evaluation).
+  // The forward has exp(-v^2/2) and erf in registers anyway, so the backward GEMM's epilogue loses ~25 VALU per element.
+  int c2_gelu_grad, mul_is_factor;
   int out_f32;
   int accumulate;
   // split-K: when split_k > 1 raw fp32 partials go to ws[split][M][N] and a second kernel reduces them into C

@@ -25,15 +25,22 @@ template <> struct Vec4<bf16> {
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue4b(const GemmParams& p, int m, int n, f32x4 v, f32x4 bias4) {
   v += bias4;
-  if (p.C2) Vec4<T>::store((T*)p.C2 + (long)m * p.ldc2 + n, v);
-  if (p.act != MMSA_ACT_NONE) {
+  if (p.C2 && p.c2_gelu_grad) {
+    f32x4 d;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+    for (int r = 0; r < 4; ++r) { const GeluPair gp = gelu_erf_both(v[r]); v[r] = gp.y; d[r] = gp.dy; }
+    Vec4<T>::store((T*)p.C2 + (long)m * p.ldc2 + n, d);
+  } else {
+    if (p.C2) Vec4<T>::store((T*)p.C2 + (long)m * p.ldc2 + n, v);
+    if (p.act != MMSA_ACT_NONE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+    }
   }
   if (p.mul) {
     f32x4 x = Vec4<T>::load((const T*)p.mul + (long)m * p.ldmul + n);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(x[r]);
+    for (int r = 0; r < 4; ++r) v[r] *= p.mul_is_factor ? x[r] : gelu_erf_grad(x[r]);
   }
   if (p.add) v += Vec4<T>::load((const T*)p.add + (long)m * p.ldadd + n);
   if (p.out_f32) {
@@ -48,15 +55,22 @@ __device__ __forceinline__ void gemm_epilogue4b(const GemmParams& p, int m, int 
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n, f32x4 v) {
   if (p.bias) v += *(const f32x4*)(p.bias + n);
-  if (p.C2) Vec4<T>::store((T*)p.C2 + (long)m * p.ldc2 + n, v);
-  if (p.act != MMSA_ACT_NONE) {
+  if (p.C2 && p.c2_gelu_grad) {
+    f32x4 d;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+    for (int r = 0; r < 4; ++r) { const GeluPair gp = gelu_erf_both(v[r]); v[r] = gp.y; d[r] = gp.dy; }
+    Vec4<T>::store((T*)p.C2 + (long)m * p.ldc2 + n, d);
+  } else {
+    if (p.C2) Vec4<T>::store((T*)p.C2 + (long)m * p.ldc2 + n, v);
+    if (p.act != MMSA_ACT_NONE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+    }
   }
   if (p.mul) {
     f32x4 x = Vec4<T>::load((const T*)p.mul + (long)m * p.ldmul + n);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(x[r]);
+    for (int r = 0; r < 4; ++r) v[r] *= p.mul_is_factor ? x[r] : gelu_erf_grad(x[r]);
   }
   if (p.add) v += Vec4<T>::load((const T*)p.add + (long)m * p.ldadd + n);
   if (p.out_f32) {
@@ -72,9 +86,18 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue1(const GemmParams& p, int m, int n, float v) {
   if (p.bias) v += p.bias[n];
-  if (p.C2) ((T*)p.C2)[(long)m * p.ldc2 + n] = from_f32<T>(v);
-  if (p.act != MMSA_ACT_NONE) v = apply_act(v, p.act);
-  if (p.mul) v *= gelu_erf_grad(to_f32<T>(((const T*)p.mul)[(long)m * p.ldmul + n]));
+  if (p.C2 && p.c2_gelu_grad) {
+    const GeluPair gp = gelu_erf_both(v);
+    v = gp.y;
+    ((T*)p.C2)[(long)m * p.ldc2 + n] = from_f32<T>(gp.dy);
+  } else {
+    if (p.C2) ((T*)p.C2)[(long)m * p.ldc2 + n] = from_f32<T>(v);
+    if (p.act != MMSA_ACT_NONE) v = apply_act(v, p.act);
+  }
+  if (p.mul) {
+    const float x = to_f32<T>(((const T*)p.mul)[(long)m * p.ldmul + n]);
+    v *= p.mul_is_factor ? x : gelu_erf_grad(x);
+  }
   if (p.add) v += to_f32<T>(((const T*)p.add)[(long)m * p.ldadd + n]);
   if (p.out_f32) {
     float* c = (float*)p.C + (long)m * p.ldc + n;

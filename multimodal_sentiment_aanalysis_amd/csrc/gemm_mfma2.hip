@@ -499,17 +499,33 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
         for (int j = 0; j < NJ; ++j) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) acc[i + h][j] += bias4[j];
-          if (p.C2) store_pair(rc2, p.ldc2, mrow + i * 16, ncol + j * 16, acc[i][j], acc[i + 1][j]);
+          if (p.C2 && p.c2_gelu_grad) {  // side output = gelu'(pre-activation), from the same exp / erf as the activation
+            f32x4 d0, d1;
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
+            for (int r = 0; r < 4; ++r) {
+              const GeluPair g0 = gelu_erf_both(acc[i][j][r]), g1 = gelu_erf_both(acc[i + 1][j][r]);
+              acc[i][j][r] = g0.y; d0[r] = g0.dy;
+              acc[i + 1][j][r] = g1.y; d1[r] = g1.dy;
+            }
+            store_pair(rc2, p.ldc2, mrow + i * 16, ncol + j * 16, d0, d1);
+          } else {
+            if (p.C2) store_pair(rc2, p.ldc2, mrow + i * 16, ncol + j * 16, acc[i][j], acc[i + 1][j]);
             if (p.act != MMSA_ACT_NONE) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) acc[i + h][j][r] = apply_act(acc[i + h][j][r], p.act);
+              for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i + h][j][r] = apply_act(acc[i + h][j][r], p.act);
             }
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
             if (has_mul) {
               const f32x4 x = unpack(side[i + h][j]);
+              if (p.mul_is_factor) acc[i + h][j] *= x;
+              else {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) acc[i + h][j][r] *= gelu_erf_grad(x[r]);
+                for (int r = 0; r < 4; ++r) acc[i + h][j][r] *= gelu_erf_grad(x[r]);
+              }
             }
           }
         }
