@@ -68,51 +68,59 @@ __global__ __launch_bounds__(256) void stem_im2col_fixed_kernel(const float* __r
   }
 }
 
-// Same matrix, thread = one fixed 8-element k chunk walking over pixels: the (channel, ky, kx) decode of the chunk's
-// eight elements is done once per thread instead of once per element and pixel (the kernel above is VALU-bound:
-// ~240 VALU per 16 bytes stored, 180 us for the 308 MB matrix against ~70 us of HBM time). Block = KCH chunks x 8 pixels.
-template <typename T, int CIN, int KW_, int KH_, int KCH>
-__global__ __launch_bounds__(KCH * 8) void stem_im2col_chunk_kernel(const float* __restrict__ img, T* __restrict__ col, int B,
-                                                                    int H, int W, int OH, int OW, int stride, int pad) {
-  constexpr int Kreal = KH_ * KW_ * CIN, Kpad = KCH * 8;
-  const int chunk = threadIdx.x % KCH, pl = threadIdx.x / KCH;
-  int off[8], dky[8], dkx[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int k = chunk * 8 + e;
-    const int ci = k % CIN, tap = k / CIN;
-    dkx[e] = tap % KW_; dky[e] = k < Kreal ? tap / KW_ : -100000;  // padded k: the row check fails
-    off[e] = (ci * H + dky[e]) * W + dkx[e];
-  }
+// Same matrix through an LDS transpose. The chunk-per-lane forms read the image with every lane of a wave on a
+// different (channel, tap): ~24 cache lines per load instruction, address-coalescing bound at 1.5-1.7 TB/s of output
+// (180-200 us for the 308 MB matrix). Here a block owns 64 consecutive output pixels; for each k the 64 lanes of a wave
+// read the same (channel, tap) of 64 neighbouring pixels (one or two image rows, stride-2 floats: 4-5 lines), drop the
+// bf16 value into LDS [pixel][k], and the block then streams its 64 x Kpad rows — one contiguous 24 KB range of the
+// matrix — out with 16-byte stores.
+template <typename T, int CIN, int KW_, int KH_, int KPAD>
+__global__ __launch_bounds__(256) void stem_im2col_lds_kernel(const float* __restrict__ img, T* __restrict__ col, int B, int H,
+                                                              int W, int OH, int OW, int stride, int pad, FastDiv fd_ow,
+                                                              FastDiv fd_oh) {
+  constexpr int Kreal = KH_ * KW_ * CIN, PIX = 64, LDW = KPAD + 2;  // row pitch 97 dwords (bf16): conflict-free columns
+  __shared__ T tile[PIX * LDW];
   const int npix = B * OH * OW;
-  for (int m = blockIdx.x * 8 + pl; m < npix; m += gridDim.x * 8) {
-    const int ox = m % OW, t = m / OW;
-    const int oy = t % OH, b = t / OH;
+  const int p = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  for (int m0 = blockIdx.x * PIX; m0 < npix; m0 += gridDim.x * PIX) {
+    const int m = m0 + p;
+    const bool pv = m < npix;
+    const uint32_t t = fd_div((uint32_t)(pv ? m : 0), fd_ow);
+    const int ox = (pv ? m : 0) - (int)t * OW;
+    const uint32_t b = fd_div(t, fd_oh);
+    const int oy = (int)t - (int)b * OH;
     const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
-    const float* ib = img + ((long)b * CIN * H + iy0) * W + ix0;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bool ok = (unsigned)(iy0 + dky[e]) < (unsigned)H && (unsigned)(ix0 + dkx[e]) < (unsigned)W;
-      v[e] = ok ? ib[off[e]] : 0.f;
+    const float* ib = img + (long)b * CIN * H * W;
+#pragma unroll 4
+    for (int k = kg; k < KPAD; k += 4) {
+      const int ci = k % CIN, tap = k / CIN;
+      const int kx = tap % KW_, ky = tap / KW_;
+      const int iy = iy0 + ky, ix = ix0 + kx;
+      const bool ok = pv && k < Kreal && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const float x = ib[ok ? (ci * H + iy) * W + ix : 0];
+      tile[p * LDW + k] = from_f32<T>(ok ? x : 0.f);
     }
-    T* dst = col + (long)m * Kpad + chunk * 8;
-    Vec4<T>::store(dst, f32x4{v[0], v[1], v[2], v[3]});
-    Vec4<T>::store(dst + 4, f32x4{v[4], v[5], v[6], v[7]});
+    __syncthreads();
+    constexpr int CH = KPAD * (int)sizeof(T) / 16;  // 16-byte chunks per row
+    for (int q = threadIdx.x; q < PIX * CH; q += 256) {
+      const int row = q / CH, c = q - row * CH;
+      if (m0 + row < npix) {
+        const uint32_t* src = (const uint32_t*)(tile + row * LDW) + c * 4;
+        const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
+        *(uint4*)((char*)(col + (long)(m0 + row) * KPAD) + c * 16) = v;
+      }
+    }
+    __syncthreads();
   }
 }
 
 int stem_im2col(int dtype, const float* img, void* col, int B, int Cin, int H, int W, int OH, int OW, int KH, int KW,
                 int stride, int pad, int Kpad, hipStream_t st) {
   if (Kpad % 4) return MMSA_ERR_ARG;
-  if (Cin == 3 && KH == 7 && KW == 7 && Kpad == 192 && (long)B * OH * OW < 0x7FFFFFF0L / 8) {
-    const int grid = (int)min(((long)B * OH * OW + 7) / 8, 8192L);
-    if (dtype == MMSA_BF16)
-      hipLaunchKernelGGL((stem_im2col_chunk_kernel<bf16, 3, 7, 7, 24>), dim3(grid), dim3(192), 0, st, img, (bf16*)col, B, H, W,
-                         OH, OW, stride, pad);
-    else
-      hipLaunchKernelGGL((stem_im2col_chunk_kernel<float, 3, 7, 7, 24>), dim3(grid), dim3(192), 0, st, img, (float*)col, B, H,
-                         W, OH, OW, stride, pad);
+  if (Cin == 3 && KH == 7 && KW == 7 && Kpad == 192 && dtype == MMSA_BF16 && (long)B * OH * OW < 0x7FFFFF00L) {
+    const int grid = (int)min(((long)B * OH * OW + 63) / 64, 8192L);
+    hipLaunchKernelGGL((stem_im2col_lds_kernel<bf16, 3, 7, 7, 192>), dim3(grid), dim3(256), 0, st, img, (bf16*)col, B, H, W, OH,
+                       OW, stride, pad, make_fastdiv((uint32_t)OW), make_fastdiv((uint32_t)OH));
     MMSA_CHECK_LAUNCH();
     return MMSA_OK;
   }
@@ -185,27 +193,29 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     const int ix = (int)(m % W);
     const long t = m / W;
     const int iy = (int)(t % H), b = (int)(t / H);
+    // the (at most 2 x 2) output windows [2o-1, 2o+1] that contain this pixel: o = i/2 and, for odd i, (i+1)/2.
+    // Branch-free: all four candidates are loaded (clamped addresses) and the invalid ones masked, so the eight loads
+    // are in flight together instead of one round trip per taken branch.
     f32x4 g = {0, 0, 0, 0};
-    // output rows whose window [2oy-1, 2oy+1] contains iy
-    const int oy_lo = iy / 2, oy_hi = (iy + 1) / 2;
-    const int ox_lo = ix / 2, ox_hi = (ix + 1) / 2;
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      if (oy >= OH) continue;
-      const int ky = iy - (2 * oy - 1);
-      if (ky < 0 || ky > 2) continue;
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        if (ox >= OW) continue;
-        const int kx = ix - (2 * ox - 1);
-        if (kx < 0 || kx > 2) continue;
-        const long om = ((long)b * OH + oy) * OW + ox;
-        const uchar4 id = *(const uchar4*)(idx + om * C + c);
-        const f32x4 d = Vec4<T>::load(dy + om * C + c);
-        const int tap = ky * 3 + kx;
-        if (id.x == tap) g[0] += d[0];
-        if (id.y == tap) g[1] += d[1];
-        if (id.z == tap) g[2] += d[2];
-        if (id.w == tap) g[3] += d[3];
-      }
+    uchar4 id[4];
+    f32x4 d[4];
+    int tap[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int oy = iy / 2 + (q >> 1), ox = ix / 2 + (q & 1);
+      const bool ok = ((q >> 1) == 0 || (iy & 1)) && ((q & 1) == 0 || (ix & 1)) && oy < OH && ox < OW;
+      const int oyc = ok ? oy : 0, oxc = ok ? ox : 0;
+      const long om = ((long)b * OH + oyc) * OW + oxc;
+      id[q] = *(const uchar4*)(idx + om * C + c);
+      d[q] = Vec4<T>::load(dy + om * C + c);
+      tap[q] = ok ? (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1)) : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (id[q].x == tap[q]) g[0] += d[q][0];
+      if (id[q].y == tap[q]) g[1] += d[q][1];
+      if (id[q].z == tap[q]) g[2] += d[q][2];
+      if (id[q].w == tap[q]) g[3] += d[q][3];
     }
     Vec4<T>::store(dx + m * C + c, g);
   }
