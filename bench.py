@@ -23,10 +23,12 @@ import torch.distributed as dist  # noqa: E402
 
 FWD_GFLOP_PER_PAIR = 30.52  # BERT-base S=128 22.348 + ResNet-50 (no fc) 8.174, 2 FLOP/MAC
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-# Algorithmic HBM bytes of an average MFMA GEMM launch of this step (275 launches per step — the four weight gradients of
-# a BERT layer are one launch — 21.78 GFLOP each on average): A + B read once (a 3x3 implicit-GEMM gather counts each
-# source pixel once), C written once (fp32 for weight gradients). Computed from profiles/r01_gemm_shapes.csv.
-ALG_BYTES_PER_GEMM_LAUNCH = 60.83e6
+# Algorithmic HBM bytes of an average MFMA GEMM launch of this step (284 launches per step — the four weight and two bias
+# gradients of a BERT layer are one launch, a stride-2 3x3 data gradient is four — ~20.6 GFLOP each on average): every
+# distinct operand of a launch read once (a 3x3 implicit-GEMM gather counts each source pixel once), C written once (fp32
+# for weight gradients): 16.73 GB per step over the per-shape table (profiles/r01_gemm_shapes.csv) + 67 MB for the
+# parity classes' re-reads of dY = 16.80 GB / 284.
+ALG_BYTES_PER_GEMM_LAUNCH = 59.15e6
 
 
 def synth_batch(B, S, vocab, device, seed):

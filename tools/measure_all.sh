@@ -1,0 +1,13 @@
+#!/bin/bash
+# The round's measurement set on the GPU box: tools/measure_all.sh <prefix>  (then, back home: tools/publish_profiles.sh <prefix>)
+set -e -o pipefail
+P=${1:-f}
+python -m pytest tests -m gpu -q > gpurun_out/${P}_tests.log 2>&1 || { tail -20 gpurun_out/${P}_tests.log; exit 1; }
+tail -1 gpurun_out/${P}_tests.log
+MMSA_PROF_DUMP=gpurun_out/${P}_shapes.csv python3 bench.py > gpurun_out/${P}_bench.json 2> gpurun_out/${P}_bench.err
+cut -c1-160 gpurun_out/${P}_bench.json
+R=$GRAFT_REPO_ROOT
+(cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/${P}_prof && MMSA_BENCH_NOPROF=1 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${P}_prof -o run -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${P}_prof.log 2>&1)
+echo "rocprof done"
+bash tools/run_pmc.sh
+echo "pmc done"
