@@ -193,3 +193,28 @@ def test_g2_group(dev):
         assert rc == 0, rc
         for (A, B, C), ref in zip(jobs, refs):
             close(C.double(), ref, f"group K={Kd} {tuple(C.shape)}", tol=2e-5)
+
+
+def test_g2_group_with_bias_problems(dev):
+    """A BERT-base layer's group as the engine launches it: four weight gradients plus two bias gradients expressed as
+    dY^T x ones[K][8] (every column of the [N][8] result is the column sum of dY), six problems in one launch."""
+    Kd = 8192
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    jobs, refs = [], []
+    dys = []
+    for i, (M, N) in enumerate(shapes):
+        A = rnd((Kd, M), dev, 10 + i, 0.5)
+        B = rnd((Kd, N), dev, 20 + i, 0.5)
+        C = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+        jobs.append((A, B, C))
+        refs.append(A.double().T @ B.double())
+        dys.append(A)
+    ones = torch.ones((Kd, 8), dtype=BF, device=dev)
+    for A in (dys[1], dys[3]):
+        C = torch.full((A.shape[1], 8), float("nan"), dtype=torch.float32, device=dev)
+        jobs.append((A, ones, C))
+        refs.append(A.double().sum(0)[:, None].expand(-1, 8))
+    rc = K.gemm_group(jobs)
+    assert rc == 0, rc
+    for (A, B, C), ref in zip(jobs, refs):
+        close(C.double(), ref, f"group+bias {tuple(C.shape)}", tol=2e-5)
