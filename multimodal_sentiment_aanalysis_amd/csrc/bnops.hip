@@ -92,14 +92,25 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restri
   }
 }
 
-// finalize kernels: 256 threads = 16 columns x 16 partial-lanes (fixed summation tree, see partial_finalize_kernel)
+// finalize kernels: 256 threads = 4 columns x 64 partial-lanes (thread = lane * 4 + column). The 64 lanes of a column
+// are summed by a fixed tree: xor-shuffles over the 16 lanes a wave holds, then the four waves through LDS (a single
+// thread walking 64 LDS values in double took ~3 us of these 6 us launches; 114 of them per step).
 #define BN_FIN_COLS 4
 #define BN_FIN_LANES 64
+template <typename V>
+__device__ __forceinline__ V bn_fin_reduce(V v, V* red /* [4][BN_FIN_COLS] */) {
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);  // lanes with the same column inside the wave
+  const int cc = threadIdx.x & (BN_FIN_COLS - 1), wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < BN_FIN_COLS) red[wave * BN_FIN_COLS + cc] = v;
+  __syncthreads();
+  return red[cc] + red[BN_FIN_COLS + cc] + red[2 * BN_FIN_COLS + cc] + red[3 * BN_FIN_COLS + cc];
+}
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int M, int C,
                                                                 float eps, float momentum, float* __restrict__ mean,
                                                                 float* __restrict__ invstd, float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var) {
-  __shared__ double rs[BN_FIN_LANES][BN_FIN_COLS + 1], rq[BN_FIN_LANES][BN_FIN_COLS + 1];
+  __shared__ double rs[4 * BN_FIN_COLS], rq[4 * BN_FIN_COLS];
   const int cc = threadIdx.x & (BN_FIN_COLS - 1), r = threadIdx.x / BN_FIN_COLS;
   const int c = blockIdx.x * BN_FIN_COLS + cc;
   double s = 0, q = 0;
@@ -108,13 +119,9 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
       s += part[((long)b * 2 + 0) * C + c];
       q += part[((long)b * 2 + 1) * C + c];
     }
-  rs[r][cc] = s;
-  rq[r][cc] = q;
-  __syncthreads();
+  s = bn_fin_reduce(s, rs);
+  q = bn_fin_reduce(q, rq);
   if (r != 0 || c >= C) return;
-  s = 0; q = 0;
-#pragma unroll
-  for (int k = 0; k < BN_FIN_LANES; ++k) { s += rs[k][cc]; q += rq[k][cc]; }
   const double mu = s / M;
   double var = q / M - mu * mu;
   if (var < 0) var = 0;
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C,
                                                               float* __restrict__ sums, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate) {
-  __shared__ float rs[BN_FIN_LANES][BN_FIN_COLS + 1], rq[BN_FIN_LANES][BN_FIN_COLS + 1];
+  __shared__ float rs[4 * BN_FIN_COLS], rq[4 * BN_FIN_COLS];
   const int cc = threadIdx.x & (BN_FIN_COLS - 1), r = threadIdx.x / BN_FIN_COLS;
   const int c = blockIdx.x * BN_FIN_COLS + cc;
   float s = 0, q = 0;
@@ -269,13 +276,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
       s += part[((long)b * 2 + 0) * C + c];
       q += part[((long)b * 2 + 1) * C + c];
     }
-  rs[r][cc] = s;
-  rq[r][cc] = q;
-  __syncthreads();
+  s = bn_fin_reduce(s, rs);
+  q = bn_fin_reduce(q, rq);
   if (r != 0 || c >= C) return;
-  s = 0; q = 0;
-#pragma unroll
-  for (int k = 0; k < BN_FIN_LANES; ++k) { s += rs[k][cc]; q += rq[k][cc]; }
   sums[c] = s;
   sums[C + c] = q;
   if (dgamma) {
