@@ -394,3 +394,63 @@ def test_bf16_mfma_engines_match_simt_engines(dev):
         o2, g2 = _run_engine_grads(mk, rn, "1")
         assert rel_err(o1, o2) < 2e-2, f"{nm} forward MFMA vs SIMT {rel_err(o1, o2)}"
         _check_grads(g1, g2, tol, f"{nm} bf16 MFMA vs SIMT", l2=True)
+
+
+def test_full_size_resnet50_mfma_vs_simt_forward(dev):
+    """ResNet-50 at its real widths (64..2048 channels, K up to 4608, 224x224: every tile shape, K split, the 147->192
+    padded stem) on the MFMA kernels against the same engine on the SIMT kernels: same bf16 rounding points, independent
+    GEMM code. Forward only: 53 train-mode BatchNorms make the bf16 backward of two correct implementations diverge
+    (see test_bf16_mfma_engines_match_simt_engines); the backward at these widths is covered per convolution in
+    test_gemm2_gpu.py::test_g2_conv and test_kernels_gpu.py::test_conv_implicit_gemm."""
+    g = torch.Generator().manual_seed(21)
+    image = torch.randn(4, 3, 224, 224, generator=g)
+
+    def make():
+        n = ResNetImageNet(None)  # default configuration = ResNet-50
+        n.precision = "bf16"
+        return n.to(dev).eval()  # eval: running statistics (identity at init) keep the comparison well conditioned
+
+    def run(n):
+        with torch.no_grad():
+            return n(image.to(dev))
+
+    outs = []
+    for flag in ("0", "1"):
+        import os
+        os.environ["MMSA_BF16_SIMT"] = flag
+        try:
+            torch.manual_seed(0)
+            outs.append(run(make()).float().cpu())
+        finally:
+            os.environ.pop("MMSA_BF16_SIMT", None)
+    assert torch.isfinite(outs[0]).all()
+    assert rel_err(outs[0], outs[1]) < 2e-2, f"ResNet-50 features MFMA vs SIMT {rel_err(outs[0], outs[1])}"
+
+
+def test_full_size_train_step_properties(dev):
+    """The benchmark's model (BERT-base + ResNet-50 + fusion head, bf16) at B = 16: properties that need no oracle.
+    (1) the loss of a fixed batch goes down over optimizer steps; (2) a second run from the same seed reproduces the
+    first loss exactly (the forward has no atomics) and the later ones closely (every reduction is order-fixed except
+    the word-embedding scatter, whose fp32 atomics reorder the sums of repeated tokens)."""
+    from multimodal_sentiment_aanalysis_amd.fused import FusedTrainStep
+    image, ids, mask, labels = synth_batch(16, 128, 224, 224, 30522, seed=5)
+    batch = (image.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
+
+    def run():
+        torch.manual_seed(0)
+        model = mm.MultimodalTransformerModel(dropout=0.0)
+        step = FusedTrainStep(model, dev, precision="bf16", lr=1e-4)
+        losses = []
+        for _ in range(4):
+            loss, _ = step.step(*batch)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        return losses
+
+    l1 = run()
+    l2 = run()
+    assert all(v == v and abs(v) < 1e4 for v in l1), l1
+    assert l1[-1] < l1[0], f"loss did not decrease on a fixed batch: {l1}"
+    assert l1[0] == l2[0], (l1, l2)
+    for a, b in zip(l1, l2):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (l1, l2)
