@@ -103,8 +103,8 @@ class FusedTrainStep:
             dist.broadcast(self.state.flat_w, 0)
             dist.broadcast(self.state.flat_bn, 0)
         # optional: the image encoder on its own HIP stream beside the text encoder (joined before the head / the
-        # optimizer). Measured on MI355X: no gain (22.96 vs 22.74 ms/step) — the persistent GEMM workgroups take the
-        # whole register file of their CU, so the other stream's kernels queue behind them; off by default.
+        # optimizer). Measured on MI355X: a loss (19.50 vs 19.23 ms/step single-stream) — the persistent GEMM workgroups
+        # take the whole register file of their CU, so the two streams' kernels only stretch each other; off by default.
         self._image_net = getattr(getattr(model, "encoder", None), "image_net", None)
         if self._image_net is not None and self.device.type == "cuda" and two_streams:
             self._image_net.use_side_stream(True)
