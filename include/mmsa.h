@@ -197,6 +197,22 @@ int mmsa_head_bwd(int32_t kind, const mmsa_head_cfg* c, const float* w, const fl
 int mmsa_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits, float* probs, int32_t B,
                     int32_t C, float grad_scale, void* stream);
 
+/* ---- N1: the reference's contrastive losses, fused forward + backward ---------------------------------
+ * mmsa_infonce_fwd_bwd: MultimodalTransformerModel.compute_contrastive_loss (MultimodalModel.py:232-260):
+ *   f = x / max(||x||, 1e-12); S = f1 f2^T / T; positives = same label, diagonal excluded; S -= rowmax(S);
+ *   loss = mean_i -log((sum_j e^S pos + 1e-12) / (sum_j e^S + 1e-12)).  temperature: device scalar (nn.Parameter :229).
+ *   Outputs: loss (device scalar), dfeat1 / dfeat2 [B][D] = grad_scale * dloss/dfeat (distinct buffers; the reference's
+ *   forward passes the same tensor twice (:272-284): the caller adds the two), dtemp = grad_scale * dloss/dT (may be NULL).
+ * mmsa_supcon_fwd_bwd: contrastive_loss(z1, z2, labels, temperature=0.1) of train.py:16-40 (two views, [2B, 2B] similarity,
+ *   diagonal removed from the denominator, +1e-8 terms as there).
+ * ws: mmsa_contrastive_ws_bytes(B, D) bytes of device memory. fp32 features, int64 labels [B]. B <= 1024, D <= 4096. */
+size_t mmsa_contrastive_ws_bytes(int32_t B, int32_t D);
+int mmsa_infonce_fwd_bwd(const float* feat1, const float* feat2, const int64_t* labels, const float* temperature, float* loss,
+                         float* dfeat1, float* dfeat2, float* dtemp, int32_t B, int32_t D, float grad_scale, void* ws,
+                         void* stream);
+int mmsa_supcon_fwd_bwd(const float* z1, const float* z2, const int64_t* labels, float temperature, float* loss, float* dz1,
+                        float* dz2, int32_t B, int32_t D, float grad_scale, void* ws, void* stream);
+
 /* ---- step tail over flat buffers: clip_grad_norm_(1.0) + AdamW (Trainer.py:19-21,80-81) ---------------------------
  * mmsa_grad_norm: norm_out[0] = grad_scale * ||g||_2, norm_out[1] = min(1, max_norm / (norm + 1e-6)) (device memory).
  * mmsa_adamw_step: decoupled-decay AdamW on w using g * norm_clip[1] * grad_scale; also refreshes the bf16 working

@@ -151,7 +151,7 @@ class MultimodalTransformerModel(HeadEngine):
         self.cross_attn_t2i = CrossModalTransformer()
         self.cross_attn_i2t = CrossModalTransformer()
         self._init_head()
-        # learnable scalars of the reference (MultimodalModel.py:228,230); used by the contrastive term (next row, N1)
+        # learnable scalars of the reference (MultimodalModel.py:228,230), used by compute_contrastive_loss (N1)
         self.contrastive_weight = nn.Parameter(torch.ones(1))
         self.temperature = nn.Parameter(torch.tensor(float(temperature)))
 
@@ -162,6 +162,11 @@ class MultimodalTransformerModel(HeadEngine):
 
     def _out_dims(self):
         return [self.num_classes, 128] + ([self.num_classes] if self.multitask else [])
+
+    def compute_contrastive_loss(self, feat1, feat2, labels):
+        """MultimodalModel.py:232-260 (supervised InfoNCE, learnable temperature) as one fused HIP launch (N1)."""
+        from .engine import supervised_infonce
+        return supervised_infonce(feat1, feat2, labels, self.temperature)
 
     def forward(self, image, token_ids, attention_mask=None, labels=None):
         self._prepare(image.device)  # one flat buffer for the whole model
@@ -174,8 +179,11 @@ class MultimodalTransformerModel(HeadEngine):
         if self.multitask:
             if labels is None:
                 return logits, outs[2]
-            z = torch.zeros(1, device=logits.device)
-            return logits, outs[2], z, z, z
+            # MultimodalModel.py:270-284,315-317: one InfoNCE term per modality feature against the arousal labels, each
+            # scaled by the learnable contrastive_weight (the three slots are the fusion token, text and image features)
+            arousal = labels[0] if isinstance(labels, (tuple, list)) else labels
+            c = [self.contrastive_weight * self.compute_contrastive_loss(f, f, arousal) for f in (mm, t, i)]
+            return logits, outs[2], c[0], c[1], c[2]
         if labels is None:
             return logits
         return logits, torch.zeros(1, device=logits.device)

@@ -125,6 +125,9 @@ def _declare(L):
         "mmsa_head_fwd": (ctypes.c_int, [i32, P(HeadCfg), vp, vp, pp, pp, vp, vp]),
         "mmsa_head_bwd": (ctypes.c_int, [i32, P(HeadCfg), vp, pp, pp, pp, vp, i32, vp, vp]),
         "mmsa_ce_fwd_bwd": (ctypes.c_int, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+        "mmsa_contrastive_ws_bytes": (sz, [i32, i32]),
+        "mmsa_infonce_fwd_bwd": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp]),
+        "mmsa_supcon_fwd_bwd": (ctypes.c_int, [vp, vp, vp, f32, vp, vp, vp, i32, i32, f32, vp, vp]),
         "mmsa_grad_norm_ws_bytes": (sz, []),
         "mmsa_grad_norm": (ctypes.c_int, [vp, i64, f32, f32, vp, vp, vp]),
         "mmsa_adamw_step": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp]),

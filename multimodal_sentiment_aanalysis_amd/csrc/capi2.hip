@@ -44,4 +44,20 @@ int mmsa_stem_im2col(int32_t dtype, const float* img, void* col, int32_t B, int3
   return stem_im2col(dtype, img, col, B, Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad, (hipStream_t)stream);
 }
 
+/* N1: fused contrastive losses (contrastive.hip) */
+size_t mmsa_contrastive_ws_bytes(int32_t B, int32_t D) { return (B > 0 && D > 0) ? contrastive_ws_bytes(B, D) : 0; }
+int mmsa_infonce_fwd_bwd(const float* feat1, const float* feat2, const int64_t* labels, const float* temperature, float* loss,
+                         float* dfeat1, float* dfeat2, float* dtemp, int32_t B, int32_t D, float grad_scale, void* ws,
+                         void* stream) {
+  if (!feat1 || !feat2 || !labels || !temperature || !loss || !dfeat1 || !dfeat2 || !ws || dfeat1 == dfeat2) return MMSA_ERR_ARG;
+  return infonce_fwd_bwd(feat1, feat2, (const long long*)labels, temperature, loss, dfeat1, dfeat2, dtemp, B, D, grad_scale,
+                         (float*)ws, (hipStream_t)stream);
+}
+int mmsa_supcon_fwd_bwd(const float* z1, const float* z2, const int64_t* labels, float temperature, float* loss, float* dz1,
+                        float* dz2, int32_t B, int32_t D, float grad_scale, void* ws, void* stream) {
+  if (!z1 || !z2 || !labels || !loss || !dz1 || !dz2 || !ws) return MMSA_ERR_ARG;
+  return supcon_fwd_bwd(z1, z2, (const long long*)labels, temperature, loss, dz1, dz2, B, D, grad_scale, (float*)ws,
+                        (hipStream_t)stream);
+}
+
 }  // extern "C"

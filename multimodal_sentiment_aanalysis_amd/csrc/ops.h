@@ -34,6 +34,13 @@ int tanh_bwd(int dtype, const void* dy, const void* y, void* dx, long n, hipStre
 int bias_pick(const float* src, float* dst, int n, const float* src2, float* dst2, int n2, hipStream_t st);
 int fill_ones_bf16(void* dst, long n, hipStream_t st);
 
+// contrastive.hip (N1)
+size_t contrastive_ws_bytes(int B, int D);
+int infonce_fwd_bwd(const float* feat1, const float* feat2, const long long* labels, const float* temperature, float* loss,
+                    float* dfeat1, float* dfeat2, float* dtemp, int B, int D, float grad_scale, float* ws, hipStream_t st);
+int supcon_fwd_bwd(const float* z1, const float* z2, const long long* labels, float temperature, float* loss, float* dz1,
+                   float* dz2, int B, int D, float grad_scale, float* ws, hipStream_t st);
+
 // bnops.hip
 size_t bn_ws_bytes(int C);
 int bn_forward(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,

@@ -589,3 +589,74 @@ class CrossEntropyLoss(nn.Module):
 
     def forward(self, logits, labels):
         return CrossEntropyFn.apply(logits, labels)
+
+
+# ------------------------------------------------------------------------------------------------ N1: contrastive losses
+def _contrastive_ws(B, D, device):
+    from .kernels import workspace
+    return workspace(_lib.load().mmsa_contrastive_ws_bytes(B, D), device, "contrastive")
+
+
+class InfoNCEFn(torch.autograd.Function):
+    """Fused forward + backward of the reference's supervised InfoNCE with learnable temperature
+    (`MultimodalTransformerModel.compute_contrastive_loss`, MultimodalModel.py:232-260): mmsa_infonce_fwd_bwd."""
+
+    @staticmethod
+    def forward(ctx, feat1, feat2, labels, temperature):
+        _require_gpu(feat1, "InfoNCE")
+        same = feat1 is feat2 or (feat1.data_ptr() == feat2.data_ptr() and feat1.shape == feat2.shape)
+        f1 = feat1.to(torch.float32).contiguous()
+        f2 = f1 if same else feat2.to(torch.float32).contiguous()
+        lb = labels.long().contiguous()
+        t = temperature.detach().to(torch.float32).reshape(-1)[:1].contiguous()
+        B, D = f1.shape
+        loss = torch.empty((), dtype=torch.float32, device=f1.device)
+        d1, d2 = torch.empty_like(f1), torch.empty_like(f1)
+        dt = torch.empty(1, dtype=torch.float32, device=f1.device)
+        ws = _contrastive_ws(B, D, f1.device)
+        check(_lib.load().mmsa_infonce_fwd_bwd(ptr(f1), ptr(f2), ptr(lb), ptr(t), ptr(loss), ptr(d1), ptr(d2), ptr(dt), B, D,
+                                               1.0, ptr(ws), stream_ptr()), "mmsa_infonce_fwd_bwd")
+        ctx.same = same
+        ctx.tshape = temperature.shape
+        ctx.save_for_backward(d1, d2, dt)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d1, d2, dt = ctx.saved_tensors
+        # both arguments were the same tensor: autograd adds the two returned gradients
+        return d1 * g, d2 * g, None, (dt * g).reshape(ctx.tshape)
+
+
+class SupConFn(torch.autograd.Function):
+    """Fused forward + backward of the two-view supervised contrastive loss (`contrastive_loss`, train.py:16-40)."""
+
+    @staticmethod
+    def forward(ctx, z1, z2, labels, temperature):
+        _require_gpu(z1, "SupCon")
+        a = z1.to(torch.float32).contiguous()
+        b = z2.to(torch.float32).contiguous()
+        lb = labels.long().reshape(-1).contiguous()
+        B, D = a.shape
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        d1, d2 = torch.empty_like(a), torch.empty_like(b)
+        ws = _contrastive_ws(B, D, a.device)
+        check(_lib.load().mmsa_supcon_fwd_bwd(ptr(a), ptr(b), ptr(lb), float(temperature), ptr(loss), ptr(d1), ptr(d2), B, D,
+                                              1.0, ptr(ws), stream_ptr()), "mmsa_supcon_fwd_bwd")
+        ctx.save_for_backward(d1, d2)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d1, d2 = ctx.saved_tensors
+        return d1 * g, d2 * g, None, None
+
+
+def supervised_infonce(feat1, feat2, labels, temperature):
+    """loss = InfoNCE(feat1, feat2 | labels, temperature) — MultimodalModel.py:232-260 on the fused kernel."""
+    return InfoNCEFn.apply(feat1, feat2, labels, temperature)
+
+
+def supcon_loss(z1, z2, labels, temperature=0.1):
+    """train.py:16-40 on the fused kernel."""
+    return SupConFn.apply(z1, z2, labels, temperature)

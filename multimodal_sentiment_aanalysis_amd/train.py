@@ -1,30 +1,18 @@
 """The reference's two-stage ME-MHACL pipeline (MML_ZYC/train.py) for (image, text) pairs, same function names/signatures:
 `contrastive_loss`, `contrastive_pretrain_trainer` (train.py:45-80), `finetune_trainer` (train.py:83-138).
 
-Stage 2 (the CE path: frozen encoder -> Classifier -> CE_a + CE_v, Adam lr as given) runs fully on the HIP modules.
-Stage 1's supervised-contrastive loss on the [2B, 2B] similarity matrix is the N1 "next" row of SURVEY.md §8(f): until its
-fused kernel lands the loss itself (train.py:16-40) is evaluated with torch tensor ops on the GPU, on top of HIP encoders
-and projection head. This file is host code, like the reference's."""
+Stage 2 (the CE path: frozen encoder -> Classifier -> CE_a + CE_v, Adam lr as given) and stage 1's supervised-contrastive
+loss on the [2B, 2B] similarity matrix (train.py:16-40) run on the HIP modules / kernels.
+This file is host code, like the reference's."""
 import torch
-import torch.nn.functional as F
 import torch.optim as optim
 
-from .engine import CrossEntropyLoss
+from .engine import CrossEntropyLoss, supcon_loss
 
 
 def contrastive_loss(z1, z2, labels, temperature=0.1):
-    """train.py:16-40 (SupCon-style, two views). N1: torch ops, see module docstring."""
-    z1, z2 = F.normalize(z1, dim=1), F.normalize(z2, dim=1)
-    z = torch.cat([z1, z2], dim=0)
-    sim = torch.matmul(z, z.T) / temperature
-    labels = labels.view(-1, 1)
-    labels = torch.cat([labels, labels], dim=0)
-    mask = torch.eq(labels, labels.T).float()
-    self_mask = torch.eye(mask.size(0), dtype=torch.bool, device=z.device)
-    mask = mask.masked_fill(self_mask, 0)
-    sim_exp = torch.exp(sim).masked_fill(self_mask, 0)
-    log_prob = sim - torch.log(sim_exp.sum(dim=1, keepdim=True) + 1e-8)
-    return (-(mask * log_prob).sum(dim=1) / (mask.sum(dim=1) + 1e-8)).mean()
+    """train.py:16-40 (SupCon-style, two views): one fused forward + backward launch (mmsa_supcon_fwd_bwd)."""
+    return supcon_loss(z1, z2, labels, temperature)
 
 
 def contrastive_pretrain_trainer(encoder, projection_head, contrastive_loader, num_epochs=20, lr=1e-3, device=None):

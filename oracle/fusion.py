@@ -167,7 +167,7 @@ def cross_entropy_grad(logits, labels):
     return p / logits.shape[0]
 
 
-# ------------------------------------------------------------------------------------------------ N1 (next row)
+# ------------------------------------------------------------------------------------------------ N1
 def supervised_infonce(feat1, feat2, labels, temperature):
     """compute_contrastive_loss, MultimodalModel.py:232-260."""
     f1, f2 = l2_normalize(feat1), l2_normalize(feat2)
@@ -177,3 +177,16 @@ def supervised_infonce(feat1, feat2, labels, temperature):
     sim = sim - sim.max(dim=1, keepdim=True)[0]
     e = torch.exp(sim)
     return (-torch.log(((e * pos).sum(1) + 1e-12) / (e.sum(1) + 1e-12))).mean()
+
+
+def supcon_two_view(z1, z2, labels, temperature=0.1):
+    """contrastive_loss, train.py:16-40: two views stacked to [2B, D], S = z z^T / T, the diagonal excluded from the
+    positives and from the soft-max denominator (no max shift; +1e-8 inside the log and in the positive count)."""
+    z = torch.cat([l2_normalize(z1), l2_normalize(z2)], dim=0)
+    sim = z @ z.t() / temperature
+    lab = torch.cat([labels.view(-1), labels.view(-1)], dim=0)
+    eye = torch.eye(z.shape[0], dtype=torch.bool)
+    mask = (lab.view(-1, 1) == lab.view(1, -1)).float().masked_fill(eye, 0.0)
+    denom = torch.exp(sim).masked_fill(eye, 0.0).sum(dim=1, keepdim=True)
+    log_prob = sim - torch.log(denom + 1e-8)
+    return (-(mask * log_prob).sum(dim=1) / (mask.sum(dim=1) + 1e-8)).mean()

@@ -253,8 +253,49 @@ def gen_bert():
         hidden_row5=ob.last_hidden_state[5])
 
 
+# ------------------------------------------------------------------------------------------------ N1
+def gen_contrastive():
+    """N1: the reference's two contrastive losses, CALLED: MultimodalTransformerModel.compute_contrastive_loss
+    (MultimodalModel.py:232-260, learnable temperature; the forward calls it with feat1 is feat2, :272-284) and
+    train.contrastive_loss (train.py:16-40, two views, T = 0.1). Stored: inputs, loss, input gradients, dT."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_train", "/root/reference/MML_ZYC/train.py")
+    ref_train = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_train)
+    m = ref_head_model(4)
+    out = {}
+    for tag, B, D, T, same in (("a", 16, 256, 0.01, True), ("b", 16, 256, 0.5, False), ("c", 64, 256, 0.07, True),
+                               ("d", 5, 128, 0.2, False)):
+        with torch.no_grad():
+            m.temperature.fill_(T)
+        f1 = rnd(B, D, seed=60 + B).requires_grad_(True)
+        f2 = f1 if same else rnd(B, D, seed=61 + B).requires_grad_(True)
+        labels = torch.randint(0, 3, (B,), generator=torch.Generator().manual_seed(70 + B))
+        if tag == "d":
+            labels[:] = torch.tensor([0, 1, 2, 1, 1])  # rows 0 and 2 have no positive
+        m.temperature.grad = None
+        loss = m.compute_contrastive_loss(f1, f2, labels)
+        loss.backward()
+        out.update({f"infonce.{tag}.f1": f1, f"infonce.{tag}.labels": labels, f"infonce.{tag}.T": torch.tensor(T),
+                    f"infonce.{tag}.loss": loss, f"infonce.{tag}.df1": f1.grad, f"infonce.{tag}.dT": m.temperature.grad,
+                    f"infonce.{tag}.same": torch.tensor(int(same))})
+        if not same:
+            out.update({f"infonce.{tag}.f2": f2, f"infonce.{tag}.df2": f2.grad})
+    for tag, B, D in (("a", 16, 128), ("b", 64, 128), ("c", 6, 32)):
+        z1 = rnd(B, D, seed=80 + B).requires_grad_(True)
+        z2 = rnd(B, D, seed=81 + B).requires_grad_(True)
+        labels = torch.randint(0, 3, (B,), generator=torch.Generator().manual_seed(90 + B))
+        loss = ref_train.contrastive_loss(z1, z2, labels)
+        loss.backward()
+        out.update({f"supcon.{tag}.z1": z1, f"supcon.{tag}.z2": z2, f"supcon.{tag}.labels": labels,
+                    f"supcon.{tag}.loss": loss, f"supcon.{tag}.dz1": z1.grad, f"supcon.{tag}.dz2": z2.grad})
+    npz("n1_contrastive.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["a1", "a2", "a4", "a5", "a7", "e1"]
+    which = sys.argv[1:] or ["a1", "a2", "a4", "a5", "a7", "e1", "n1"]
+    if "n1" in which:
+        gen_contrastive()
     if "a1" in which:
         gen_cross_modal()
     if "a2" in which:

@@ -269,3 +269,58 @@ def test_trainer_and_tester_contracts(dev, tmp_path):
     assert res["probabilities"].shape == (2, 3) and abs(res["probabilities"].sum(1) - 1).max() < 1e-5
     single = t.predict_single({k: v[0] for k, v in next(iter(test))[0].items()})
     assert single["probabilities"].shape == (3,)
+
+
+def test_n1_contrastive_losses(dev):
+    """N1 on the fused HIP kernels (mmsa_infonce_fwd_bwd / mmsa_supcon_fwd_bwd) through the model-level mirrors
+    (MultimodalTransformerModel.compute_contrastive_loss, train.contrastive_loss) against the reference's own values and
+    autograd gradients (tests/golden/n1_contrastive.npz). fp32; the [B,B] soft-max at T = 0.01 spans e^±200, so the
+    tolerance is on the scale of the largest gradient entry."""
+    from multimodal_sentiment_aanalysis_amd import train as T
+    from multimodal_sentiment_aanalysis_amd.engine import supervised_infonce
+    d = load("n1_contrastive.npz")
+    for tag in "abcd":
+        same = bool(d[f"infonce.{tag}.same"].item())
+        f1 = d[f"infonce.{tag}.f1"].to(dev).requires_grad_(True)
+        f2 = f1 if same else d[f"infonce.{tag}.f2"].to(dev).requires_grad_(True)
+        temp = d[f"infonce.{tag}.T"].to(dev).requires_grad_(True)
+        loss = supervised_infonce(f1, f2, d[f"infonce.{tag}.labels"].to(dev), temp)
+        loss.backward()
+        close(loss, d[f"infonce.{tag}.loss"], 2e-5, f"infonce {tag} loss")
+        close(f1.grad, d[f"infonce.{tag}.df1"], 1e-4, f"infonce {tag} df1")
+        close(temp.grad, d[f"infonce.{tag}.dT"], 1e-4, f"infonce {tag} dT")
+        if not same:
+            close(f2.grad, d[f"infonce.{tag}.df2"], 1e-4, f"infonce {tag} df2")
+    for tag in "abc":
+        z1 = d[f"supcon.{tag}.z1"].to(dev).requires_grad_(True)
+        z2 = d[f"supcon.{tag}.z2"].to(dev).requires_grad_(True)
+        loss = T.contrastive_loss(z1, z2, d[f"supcon.{tag}.labels"].to(dev))
+        (2.0 * loss).backward()  # a non-unit upstream gradient
+        close(loss, d[f"supcon.{tag}.loss"], 2e-5, f"supcon {tag} loss")
+        close(z1.grad / 2.0, d[f"supcon.{tag}.dz1"], 1e-4, f"supcon {tag} dz1")
+        close(z2.grad / 2.0, d[f"supcon.{tag}.dz2"], 1e-4, f"supcon {tag} dz2")
+
+
+def test_n1_multitask_forward_returns_contrastive_terms(dev):
+    """MultiTaskTrainer contract (MultimodalModel.py:262,319-322): with labels the model returns
+    (arousal, valence, c1, c2, c3), c_k = contrastive_weight * InfoNCE(feature_k, feature_k | arousal labels)."""
+    from util import MINI_BERT, MINI_RESNET, synth_batch
+    from oracle import fusion as OF
+    torch.manual_seed(0)
+    m = mm.MultimodalTransformerModel(bert_config=MINI_BERT, resnet_config=MINI_RESNET, multitask=True, dropout=0.0)
+    with torch.no_grad():
+        m.temperature.fill_(0.2)
+        m.contrastive_weight.fill_(0.7)
+    image, ids, mask, labels = synth_batch(8, 16, 64, 64, MINI_BERT["vocab"], seed=3)
+    m.precision = "fp32"
+    m.to(dev).train()
+    out = m(image.to(dev), ids.to(dev), mask.to(dev), (labels.to(dev), labels.to(dev)))
+    assert len(out) == 5 and out[0].shape == (8, 3) and out[1].shape == (8, 3)
+    i, t = m.encoder.features(image.to(dev), ids.to(dev), mask.to(dev))
+    ref_t = 0.7 * OF.supervised_infonce(t.detach().cpu(), t.detach().cpu(), labels, torch.tensor(0.2))
+    ref_i = 0.7 * OF.supervised_infonce(i.detach().cpu(), i.detach().cpu(), labels, torch.tensor(0.2))
+    assert abs(out[3].item() - ref_t.item()) < 2e-5 * max(1.0, abs(ref_t.item())), (out[3].item(), ref_t.item())
+    assert abs(out[4].item() - ref_i.item()) < 2e-5 * max(1.0, abs(ref_i.item())), (out[4].item(), ref_i.item())
+    (out[0].sum() + out[2] + out[3] + out[4]).backward()
+    assert m.temperature.grad is not None and torch.isfinite(m.temperature.grad).all()
+    assert m.contrastive_weight.grad is not None

@@ -204,3 +204,30 @@ def test_resnet50_anchor():
     from oracle.resnet import RESNET50, resnet_param_shapes
     n = sum(int(np.prod(s)) for _, s, buf in resnet_param_shapes(RESNET50) if not buf)
     assert n == 23508032
+
+
+def test_n1_contrastive_losses():
+    """N1: the oracle's restatements of the reference's two contrastive losses against values and gradients produced by
+    CALLING the reference (MultimodalModel.compute_contrastive_loss :232-260 incl. feat1 is feat2 and rows without a
+    positive; train.contrastive_loss train.py:16-40)."""
+    d = load("n1_contrastive.npz")
+    for tag in "abcd":
+        same = bool(d[f"infonce.{tag}.same"].item())
+        f1 = d[f"infonce.{tag}.f1"].clone().requires_grad_(True)
+        f2 = f1 if same else d[f"infonce.{tag}.f2"].clone().requires_grad_(True)
+        T = d[f"infonce.{tag}.T"].clone().requires_grad_(True)
+        loss = OF.supervised_infonce(f1, f2, d[f"infonce.{tag}.labels"], T)
+        loss.backward()
+        close(loss, d[f"infonce.{tag}.loss"], 1e-6, f"infonce {tag} loss")
+        close(f1.grad, d[f"infonce.{tag}.df1"], 1e-5, f"infonce {tag} df1")
+        close(T.grad, d[f"infonce.{tag}.dT"], 1e-5, f"infonce {tag} dT")
+        if not same:
+            close(f2.grad, d[f"infonce.{tag}.df2"], 1e-5, f"infonce {tag} df2")
+    for tag in "abc":
+        z1 = d[f"supcon.{tag}.z1"].clone().requires_grad_(True)
+        z2 = d[f"supcon.{tag}.z2"].clone().requires_grad_(True)
+        loss = OF.supcon_two_view(z1, z2, d[f"supcon.{tag}.labels"], 0.1)
+        loss.backward()
+        close(loss, d[f"supcon.{tag}.loss"], 1e-6, f"supcon {tag} loss")
+        close(z1.grad, d[f"supcon.{tag}.dz1"], 1e-5, f"supcon {tag} dz1")
+        close(z2.grad, d[f"supcon.{tag}.dz2"], 1e-5, f"supcon {tag} dz2")
