@@ -34,27 +34,34 @@ class Tester:
         return loss, probs
 
     def evaluate(self, verbose=True):
+        """Tester.py:37-84. Per-batch results stay on the device; one host copy at the end (the reference syncs 3x / batch)."""
         self.model.eval()
-        total_loss, correct, total_samples = 0.0, 0, 0
+        loss_sum = torch.zeros((), dtype=torch.float64, device=self.device)
+        hits = torch.zeros((), dtype=torch.int64, device=self.device)
+        seen, pred_chunks, label_chunks, prob_chunks = 0, [], [], []
         with torch.no_grad():
-            for data_dict, labels in self.test_loader:
-                x1, x2, x3 = unpack(data_dict, self.device)
-                labels = labels.to(self.device)
-                outputs = self.model(x1, x2, x3)  # no labels -> bare logits (Tester.py:53)
-                loss, probs = self._ce_probs(outputs, labels)
-                total_loss += loss.item() * labels.size(0)
-                _, preds = torch.max(outputs, 1)
-                correct += (preds == labels).sum().item()
-                total_samples += labels.size(0)
-                self.all_preds.extend(preds.cpu().numpy())
-                self.all_labels.extend(labels.cpu().numpy())
-                self.all_probs.extend(probs.cpu().numpy())
-        self.loss = total_loss / total_samples
-        self.accuracy = correct / total_samples
+            for batch_inputs, batch_labels in self.test_loader:
+                feeds = unpack(batch_inputs, self.device)
+                y = batch_labels.to(self.device)
+                logits = self.model(*feeds)  # no labels -> bare logits (Tester.py:53)
+                ce, probs = self._ce_probs(logits, y)
+                n = y.shape[0]
+                winners = logits.argmax(dim=1)
+                loss_sum += ce.double() * n
+                hits += (winners == y).sum()
+                seen += n
+                pred_chunks.append(winners)
+                label_chunks.append(y)
+                prob_chunks.append(probs)
+        self.loss = float(loss_sum.item()) / seen  # an empty loader raises ZeroDivisionError, as Tester.py:71 does
+        self.accuracy = int(hits.item()) / seen
+        self.all_preds.extend(torch.cat(pred_chunks).cpu().numpy())
+        self.all_labels.extend(torch.cat(label_chunks).cpu().numpy())
+        self.all_probs.extend(torch.cat(prob_chunks).cpu().numpy())
         if verbose:
             self._print_metrics()
-        return {"loss": self.loss, "accuracy": self.accuracy, "predictions": np.array(self.all_preds),
-                "labels": np.array(self.all_labels), "probabilities": np.array(self.all_probs)}
+        return dict(loss=self.loss, accuracy=self.accuracy, predictions=np.array(self.all_preds),
+                    labels=np.array(self.all_labels), probabilities=np.array(self.all_probs))
 
     def _print_metrics(self):
         print(f"\n{'=' * 40}\nEvaluation Results:\n- Average Loss: {self.loss:.4f}\n- Accuracy: {self.accuracy:.2%}")
@@ -66,13 +73,14 @@ class Tester:
         print("=" * 40)
 
     def predict_single(self, data_dict):
+        """Tester.py:112-127: one sample (no batch dimension) -> class index + softmax vector."""
         self.model.eval()
         with torch.no_grad():
-            x1, x2, x3 = unpack(data_dict, self.device)
-            outputs = self.model(x1.unsqueeze(0), x2.unsqueeze(0), x3.unsqueeze(0))
-            _, probs = self._ce_probs(outputs, torch.zeros(1, dtype=torch.long, device=outputs.device))
-            _, pred = torch.max(outputs, 1)
-        return {"prediction": pred.item(), "probabilities": probs.squeeze().cpu().numpy()}
+            feeds = [t.unsqueeze(0) for t in unpack(data_dict, self.device)]
+            logits = self.model(*feeds)
+            dummy = torch.zeros(1, dtype=torch.long, device=logits.device)
+            probs = self._ce_probs(logits, dummy)[1]
+        return {"prediction": int(logits.argmax(dim=1).item()), "probabilities": probs.squeeze().cpu().numpy()}
 
     def run(self, model_path=None):
         if model_path is not None:

@@ -56,47 +56,58 @@ class Trainer:
         self.patience, self.counter, self.early_stop_flag = 5, 0, False
         self._plateau_bad, self._plateau_best = 0, float("inf")
 
-    # ---- one epoch (Trainer.py:42-105)
+    # ---- one epoch (Trainer.py:42-105). Running sums live on the device: one host read per epoch instead of the
+    # reference's three to four .item() syncs per batch (only the un-fused branch needs a per-batch NaN decision).
+    def _tally(self):
+        z = lambda dt: torch.zeros((), dtype=dt, device=self.device)  # noqa: E731
+        return {"loss": z(torch.float64), "ce": z(torch.float64), "aux": z(torch.float64), "hit": z(torch.int64),
+                "seen": z(torch.int64), "nan": z(torch.int64), "batches": z(torch.int64)}
+
+    @staticmethod
+    def _count(tally, logits, y, loss, ce, aux):
+        ok = ~torch.isnan(loss.detach())
+        tally["nan"] += (~ok).long()
+        tally["batches"] += ok.long()
+        tally["loss"] += torch.where(ok, loss.detach().double(), torch.zeros_like(tally["loss"]))
+        tally["ce"] += torch.where(ok, ce.detach().double(), torch.zeros_like(tally["ce"]))
+        tally["aux"] += torch.where(ok, aux.detach().double().reshape(()), torch.zeros_like(tally["aux"]))
+        tally["hit"] += torch.where(ok, (logits.detach().argmax(dim=1) == y).sum(), torch.zeros_like(tally["hit"]))
+        tally["seen"] += torch.where(ok, torch.full_like(tally["seen"], y.shape[0]), torch.zeros_like(tally["seen"]))
+
     def train_epoch(self, epoch):
         self.model.train()
-        total_loss = total_ce = total_con = 0.0
-        correct = total_samples = 0
-        for data_dict, labels in self.train_loader:
-            x1, x2, x3 = unpack(data_dict, self.device)
-            labels = labels.to(self.device)
+        tally = self._tally()
+        zero = torch.zeros((), device=self.device)
+        for batch_inputs, batch_labels in self.train_loader:
+            feeds = unpack(batch_inputs, self.device)
+            y = batch_labels.to(self.device)
             if self.fused:
-                loss_t, outputs = self.fused_step.step(x1, x2, x3, labels)
-                loss_v = ce_v = loss_t.item()
-                con_v = 0.0
-                if loss_v != loss_v:  # NaN: the reference skips the batch (Trainer.py:74-76)
-                    print("NaN loss detected, skipping batch")
-                    continue
-            else:
-                self.optimizer.zero_grad()
-                outputs, contrastive_loss = self.model(x1, x2, x3, labels)
-                if torch.isnan(outputs).any():
-                    print("Warning: Model output contains NaN!")
-                    outputs = torch.nan_to_num(outputs)
-                ce_loss = self.criterion(outputs, labels)
-                loss = ce_loss + self.contrastive_weight * contrastive_loss
-                if torch.isnan(loss):
-                    print("NaN loss detected, skipping batch")
-                    continue
-                loss.backward()
-                torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
-                self.optimizer.step()
-                loss_v, ce_v, con_v = loss.item(), ce_loss.item(), contrastive_loss.item()
-            total_loss += loss_v
-            total_ce += ce_v
-            total_con += con_v
-            _, predicted = torch.max(outputs.data, 1)
-            correct += (predicted == labels).sum().item()
-            total_samples += labels.size(0)
-        n = max(total_samples, 1)
-        acc = correct / total_samples if total_samples > 0 else 0.0
-        self.train_loss.append(total_loss / n)
+                step_loss, logits = self.fused_step.step(*feeds, y)
+                self._count(tally, logits, y, step_loss, step_loss, zero)
+                continue
+            self.optimizer.zero_grad()
+            logits, aux = self.model(*feeds, y)
+            if torch.isnan(logits).any():
+                print("Warning: Model output contains NaN!")
+                logits = torch.nan_to_num(logits)
+            ce = self.criterion(logits, y)
+            objective = ce + self.contrastive_weight * aux
+            if torch.isnan(objective):  # Trainer.py:74-76: the batch is skipped, no update
+                print("NaN loss detected, skipping batch")
+                tally["nan"] += 1
+                continue
+            objective.backward()
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
+            self.optimizer.step()
+            self._count(tally, logits, y, objective.reshape(()), ce, aux)
+        t = {k: v.item() for k, v in tally.items()}
+        if t["nan"] and self.fused:
+            print(f"NaN loss detected in {t['nan']} batch(es); they are left out of the epoch averages")
+        denom = max(t["seen"], 1)
+        acc = t["hit"] / t["seen"] if t["seen"] > 0 else 0.0
+        self.train_loss.append(t["loss"] / denom)
         self.train_acc.append(acc)
-        return total_loss / n, total_ce / n, total_con / n, acc
+        return t["loss"] / denom, t["ce"] / denom, t["aux"] / denom, acc
 
     def early_stop(self, val_loss):
         if val_loss < self.best_val_loss:
@@ -112,27 +123,20 @@ class Trainer:
 
     def _eval(self):
         self.model.eval()
-        total_loss = 0.0
-        correct = total_samples = 0
-        nbatch = 0
+        tally = self._tally()
+        zero = torch.zeros((), device=self.device)
         with torch.no_grad():
-            for data_dict, labels in self.test_loader:
-                x1, x2, x3 = unpack(data_dict, self.device)
-                labels = labels.to(self.device)
-                outputs, _ = self.model(x1, x2, x3, labels)
-                if torch.isnan(outputs).any():
-                    print("Warning: Test output contains NaN!")
-                    outputs = torch.nan_to_num(outputs)
-                loss = self.criterion(outputs, labels)
-                if torch.isnan(loss):
-                    print("NaN loss in test, skipping batch")
-                    continue
-                total_loss += loss.item()
-                _, predicted = torch.max(outputs.data, 1)
-                correct += (predicted == labels).sum().item()
-                total_samples += labels.size(0)
-                nbatch += 1
-        return total_loss, correct, total_samples, nbatch
+            for batch_inputs, batch_labels in self.test_loader:
+                feeds = unpack(batch_inputs, self.device)
+                y = batch_labels.to(self.device)
+                logits, _ = self.model(*feeds, y)
+                logits = torch.nan_to_num(logits)  # Trainer.py:135-137 repairs NaN logits; NaN losses are left out below
+                ce = self.criterion(logits, y)
+                self._count(tally, logits, y, ce, ce, zero)
+        t = {k: v.item() for k, v in tally.items()}
+        if t["nan"]:
+            print(f"NaN loss in test: {t['nan']} batch(es) skipped")
+        return t["loss"], t["hit"], t["seen"], t["batches"]
 
     def test(self):
         total_loss, correct, total_samples, _ = self._eval()
