@@ -163,6 +163,28 @@ class MultimodalTransformerModel(HeadEngine):
     def _out_dims(self):
         return [self.num_classes, 128] + ([self.num_classes] if self.multitask else [])
 
+    # the reference's attribute names (MultiTaskTrainer.py:59,79,99,120-127 reach into the model by name): slot 1 is the
+    # ME-MHACL fusion token (the whole encoder), slot 2 the text encoder, slot 3 the image encoder
+    @property
+    def eeg_net(self):
+        return self.encoder
+
+    @property
+    def eye_net(self):
+        return self.encoder.text_net
+
+    @property
+    def pps_net(self):
+        return self.encoder.image_net
+
+    @property
+    def cross_attn_e2p(self):
+        return self.cross_attn_t2i
+
+    @property
+    def cross_attn_p2e(self):
+        return self.cross_attn_i2t
+
     def compute_contrastive_loss(self, feat1, feat2, labels):
         """MultimodalModel.py:232-260 (supervised InfoNCE, learnable temperature) as one fused HIP launch (N1)."""
         from .engine import supervised_infonce

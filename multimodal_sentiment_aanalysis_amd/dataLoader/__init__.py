@@ -1,1 +1,2 @@
 from .DataLoader import MultimodalDataLoader, SyntheticPairs  # noqa: F401
+from .MultiTaskTrainer import MultiTaskTrainer  # noqa: F401

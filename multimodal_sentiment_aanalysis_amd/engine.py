@@ -143,15 +143,28 @@ class EngineModule(nn.Module):
             materialize(self, device)
 
     def _ensure_grads(self):
-        """Before a backward: make sure p.grad are the flat views (zero_grad(set_to_none=True) drops them)."""
+        """Before a backward: every trainable parameter's .grad must be its view of the flat gradient buffer.
+        zero_grad(set_to_none=True) drops the views of the parameters the optimizer owns (possibly a subset of the
+        trainable ones: MultiTaskTrainer's phase 3 trains four modules but optimizes one): those ranges restart from zero,
+        the others keep accumulating, as torch's own .grad semantics would have it."""
+        first, stale, trainable = True, [], 0
         for name, off, shape in self._specs:
             p = self._pmap[name]
             if not p.requires_grad:
                 continue
-            exp = self._flat_g.data_ptr() + off * 4
-            if p.grad is None or p.grad.data_ptr() != exp:
-                self._attach_grads(zero=True)
-            break
+            trainable += 1
+            g = p.grad
+            if g is None or (first and g.data_ptr() != self._flat_g.data_ptr() + off * 4):  # (pointer check: first only)
+                stale.append((p, off, shape))
+            first = False
+        if not stale:
+            return
+        if len(stale) == trainable and trainable == len(self._specs):
+            self._attach_grads(zero=True)  # the usual case (optimizer over everything): one memset of the flat buffer
+            return
+        for p, off, shape in stale:
+            self._flat_g[off:off + math.prod(shape)].zero_()
+            p.grad = self._view(self._flat_g, off, shape)
 
     def _acc_flag(self):
         if self._overwrite_next:

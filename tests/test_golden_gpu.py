@@ -324,3 +324,56 @@ def test_n1_multitask_forward_returns_contrastive_terms(dev):
     (out[0].sum() + out[2] + out[3] + out[4]).backward()
     assert m.temperature.grad is not None and torch.isfinite(m.temperature.grad).all()
     assert m.contrastive_weight.grad is not None
+
+
+def test_n2_multitask_trainer_phases(dev, tmp_path, monkeypatch):
+    """N2: the reference's five-phase MultiTaskTrainer surface on the HIP modules — each phase moves exactly the parameters
+    its optimizer owns (frozen sub-graphs stay bit-identical), metrics have the reference's keys, run() walks all phases."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from util import MINI_BERT, MINI_RESNET
+    from multimodal_sentiment_aanalysis_amd.dataLoader import MultiTaskTrainer
+    g = torch.Generator().manual_seed(7)
+    n = 16
+    ds = TensorDataset(torch.randn(n, 3, 64, 64, generator=g), torch.randint(0, MINI_BERT["vocab"], (n, 16), generator=g),
+                       torch.ones(n, 16), torch.randint(0, 3, (n,), generator=g), torch.randint(0, 3, (n,), generator=g))
+    loader = DataLoader(ds, batch_size=8)
+    torch.manual_seed(0)
+    model = mm.MultimodalTransformerModel(bert_config=MINI_BERT, resnet_config=MINI_RESNET, multitask=True, dropout=0.0)
+    tr = MultiTaskTrainer(model, loader, loader, device=dev, test_person=3)
+
+    def snap():
+        return {k: v.detach().clone() for k, v in model.named_parameters()}
+
+    def moved(before):
+        return {k for k, v in model.named_parameters() if not torch.equal(v.detach(), before[k])}
+
+    b = snap()
+    m1 = tr.train_epoch_phase_eye(1)
+    ch = moved(b)
+    assert ch and all(k.startswith("encoder.text_net.") for k in ch), sorted(ch)[:5]
+    assert set(m1) == {"loss", "a_loss", "v_loss", "c_loss", "a_acc", "v_acc"} and m1["a_loss"] == 0 and m1["c_loss"] > 0
+
+    b = snap()
+    tr.train_epoch_phase_pps(1)
+    ch = moved(b)
+    assert ch and all(k.startswith("encoder.image_net.") for k in ch), sorted(ch)[:5]
+
+    b = snap()
+    m2 = tr.train_epoch_phase2(1)
+    ch = moved(b)
+    assert any(k.startswith("arousal_head.") for k in ch) and any(k.startswith("encoder.") for k in ch)
+    assert not any(k.startswith("valence_head.") or k in ("temperature", "contrastive_weight") for k in ch), sorted(ch)[:5]
+    assert m2["a_loss"] > 0 and m2["c_loss"] == 0
+
+    b = snap()
+    tr.train_epoch_phase3(1)
+    ch = moved(b)
+    assert ch and all(k.startswith("valence_head.") for k in ch), sorted(ch)[:5]
+
+    ev = tr.evaluate()
+    assert all(v == v for v in ev.values()) and ev["loss"] > 0 and 0.0 <= ev["a_acc"] <= 1.0
+
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(tr, "visualize_progress", lambda: None)
+    tr.run(1, 0, 0, 1, 1)
+    assert len(tr.metrics["train"]["loss"]) == 4 + 3 and any(f.endswith(".pth") for f in os.listdir(tmp_path))
