@@ -454,3 +454,20 @@ def test_full_size_train_step_properties(dev):
     assert l1[0] == l2[0], (l1, l2)
     for a, b in zip(l1, l2):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (l1, l2)
+
+
+def test_c3_bert_large_resnet101_train_steps(dev):
+    """BASELINE.json configs[3] (BERT-large S = 256 + ResNet-101): the largest configuration runs through the same engines
+    (attention backward at S = 256 uses the blocked SIMT kernel) — a fixed batch's loss is finite and goes down."""
+    from multimodal_sentiment_aanalysis_amd.fused import FusedTrainStep
+    image, ids, mask, labels = synth_batch(4, 256, 224, 224, 30522, seed=9)
+    batch = (image.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
+    torch.manual_seed(0)
+    model = mm.MultimodalTransformerModel(bert_config=mm.BERT_LARGE, resnet_config=mm.RESNET101, dropout=0.0)
+    step = FusedTrainStep(model, dev, precision="bf16", lr=1e-4)
+    losses = [float(step.step(*batch)[0]) for _ in range(4)]
+    torch.cuda.synchronize()
+    assert all(v == v and abs(v) < 1e4 for v in losses), losses
+    assert losses[-1] < losses[0], losses
+    del step, model
+    torch.cuda.empty_cache()

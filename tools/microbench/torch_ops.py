@@ -16,3 +16,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step.step(*batch)
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=60))
+rows = [(e.key, e.count, e.self_device_time_total) for e in prof.key_averages() if e.key.startswith("aten::") or "Memcpy" in e.key or "Memset" in e.key or "elementwise" in e.key or "copyBuffer" in e.key or "fillBuffer" in e.key]
+print("\naten-level ops in one step (name, calls, self device us):")
+for k, c, t in sorted(rows, key=lambda r: -r[1]):
+    print(f"  {k[:70]:70s} {c:4d} {t:9.1f}")
