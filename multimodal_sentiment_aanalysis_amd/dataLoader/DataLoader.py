@@ -82,3 +82,69 @@ class MultimodalDataLoader:
         tr, te = self._split(test_subject_id)
         t = tr if train else te
         return DataLoader(_DictView(t[:4]), batch_size=self.batch_size, shuffle=train, pin_memory=True)
+
+
+class DevicePrefetcher:
+    """N4: double-buffered host -> device input pipeline. Wraps any loader of tensor tuples / (dict, labels)
+    batches: the next batch is copied from pinned host memory on a side HIP stream while the current one trains, the
+    consumer's stream waits on the copy's event only. The reference's loaders are 0-worker, pin_memory=True
+    (DataLoader.py:144-156) and copy synchronously inside the step (Trainer.py:53-56)."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    @property
+    def dataset(self):
+        return self.loader.dataset
+
+    def _move(self, obj):
+        if torch.is_tensor(obj):
+            src = obj if (obj.is_pinned() or self.stream is None) else obj.pin_memory()
+            return src.to(self.device, non_blocking=True)
+        if isinstance(obj, dict):
+            return {k: self._move(v) for k, v in obj.items()}
+        if isinstance(obj, (tuple, list)):
+            return type(obj)(self._move(v) for v in obj)
+        return obj
+
+    @staticmethod
+    def _tensors(obj):
+        if torch.is_tensor(obj):
+            yield obj
+        elif isinstance(obj, dict):
+            for v in obj.values():
+                yield from DevicePrefetcher._tensors(v)
+        elif isinstance(obj, (tuple, list)):
+            for v in obj:
+                yield from DevicePrefetcher._tensors(v)
+
+    def __iter__(self):
+        if self.stream is None:
+            yield from self.loader
+            return
+        it = iter(self.loader)
+
+        def fetch():
+            try:
+                host = next(it)
+            except StopIteration:
+                return None
+            with torch.cuda.stream(self.stream):
+                dev = self._move(host)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            return dev, ev
+
+        nxt = fetch()
+        while nxt is not None:
+            batch, ev = nxt
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for t in self._tensors(batch):
+                t.record_stream(cur)  # the side stream's allocation is consumed on the compute stream
+            nxt = fetch()             # the copy of batch k+1 overlaps the step on batch k
+            yield batch

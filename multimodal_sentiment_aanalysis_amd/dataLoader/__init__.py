@@ -1,2 +1,2 @@
-from .DataLoader import MultimodalDataLoader, SyntheticPairs  # noqa: F401
+from .DataLoader import DevicePrefetcher, MultimodalDataLoader, SyntheticPairs  # noqa: F401
 from .MultiTaskTrainer import MultiTaskTrainer  # noqa: F401
