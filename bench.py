@@ -2,36 +2,104 @@
 """Benchmark of the hot path: one training step (forward + CE + backward + gradient all-reduce + clip + AdamW) of
 BERT-base + ResNet-50 + the reference's attention fusion head on synthetic 224x224 RGB + 128-token batches, bs=64/GPU.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either the driver starts the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
+WORLD_SIZE is set, this process is one rank) or — WORLD_SIZE unset — this process starts them itself: it spawns
+`torch.distributed.run` as a CHILD process before anything here touches the GPU, relays the children's output (rank 0
+prints the JSON line) and exits with their status. It never re-executes itself.
 
 Prints ONE JSON line on rank 0 (BASELINE.json metric: (image,text) pairs/sec/node). `roofline` is measured live: every
-bf16 MFMA GEMM launch of the timed region is bracketed by HIP events on its launch stream (mmsa_prof_*); `cpu_baseline`
-is the CPU oracle's train step (oracle/model.py) timed on the host cores on a bounded sample (rank 0, N = 1 only).
+bf16 MFMA GEMM launch is timed by the kernels' own clock right after the timed region (mmsa_prof_*; HIP events on the
+launch stream beside it); `forward` is the forward-only pass of the same model at the same batch (the north-star's 50 %
+MFMA target is stated on the forward); `cpu_baseline` is the CPU oracle's train step (oracle/model.py) timed on the host
+cores on a bounded sample (rank 0, N = 1 only). `--mode fwd` times the forward alone as the headline number.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 FWD_GFLOP_PER_PAIR = 30.52  # SURVEY.md §8(d): BERT-base S=128 22.348 + ResNet-50 (no fc) 8.174, 2 FLOP/MAC
+C3_FWD_GFLOP_PER_PAIR = 176.66  # BERT-large S=256 161.06 + ResNet-101 15.60
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_FP32_TFLOPS = 157.3    # fp32 matrix / vector peak (precision="fp32": exact-fp32 kernels)
 # Algorithmic HBM bytes of an average MFMA GEMM launch of this step (284 launches per step — the four weight and two bias
 # gradients of a BERT layer are one launch, a stride-2 3x3 data gradient is four — ~20.6 GFLOP each on average): every
 # distinct operand of a launch read once (a 3x3 implicit-GEMM gather counts each source pixel once), C written once (fp32
 # for weight gradients): 16.73 GB per step over the per-shape table (profiles/r01_gemm_shapes.csv) + 67 MB for the
 # parity classes' re-reads of dY = 16.80 GB / 284.
 ALG_BYTES_PER_GEMM_LAUNCH = 59.15e6
+TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)   # SURVEY.md §8(d): 20 warm-up, >= 100 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; `value` is the "
+                    "FIRST region (the driver's contract), the median of all of them is reported beside it (§8(d))")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64; 32 for --model large)")
+    ap.add_argument("--seq", type=int, default=None, help="tokens per text (default 128; 256 for --model large)")
+    ap.add_argument("--model", default="base", choices=["base", "large"],
+                    help="base = BERT-base + ResNet-50 (BASELINE configs[1]); large = BERT-large + ResNet-101 (configs[3])")
+    ap.add_argument("--mode", default="train", choices=["train", "fwd"],
+                    help="train = the BASELINE metric; fwd = forward only (training-mode BatchNorm, no backward)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-baseline-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: every step takes its batch from "
+                    "pinned host memory through the double-buffered DevicePrefetcher (the default keeps inputs resident)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank code path on a single GPU)")
+    ap.add_argument("--print-launch", action="store_true", help="print the child command of the self-launch and exit")
+    args = ap.parse_args(argv)
+    if args.batch is None:
+        args.batch = 32 if args.model == "large" else 64
+    if args.seq is None:
+        args.seq = 256 if args.model == "large" else 128
+    return args
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def child_command(argv, gpus, port):
+    """The command the self-launch runs: torch.distributed.run with one rank per GPU on this node, this script and the
+    caller's own arguments (so the children parse exactly what the parent parsed)."""
+    args = [a for a in argv if a != "--print-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+
+
+def self_launch(args, argv):
+    """WORLD_SIZE is unset and --gpus N > 1: start the N ranks as children. Nothing in this process has touched the GPU
+    (no torch.cuda call, not even an import of torch), and nothing is exec'ed: the children are ordinary subprocesses."""
+    cmd = child_command(argv, args.gpus, free_port())
+    if args.print_launch:
+        print(json.dumps(cmd))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def synth_batch(B, S, vocab, device, seed):
+    import torch
     g = torch.Generator().manual_seed(seed)
     image = torch.randn(B, 3, 224, 224, generator=g)
     ids = torch.randint(0, vocab, (B, S), generator=g)
@@ -43,6 +111,7 @@ def synth_batch(B, S, vocab, device, seed):
 
 def cpu_baseline(model, B, steps):
     """Reference-style train step of the CPU oracle (fp32) on the host cores: the reported baseline, not the product."""
+    import torch
     from oracle import model as OM
     from oracle.bert import BERT_BASE as OB
     from oracle.resnet import RESNET50 as OR
@@ -71,30 +140,29 @@ def cpu_baseline(model, B, steps):
 
 
 def pmc_traffic():
-    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json, produced by
-    tools/pmc_traffic.py on the GPU box; bench.py cannot run the profiler around itself). None when absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["all_gemm"]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes (tools/run_pmc.sh + tools/pmc_traffic.py on the
+    GPU box; bench.py cannot run the profiler around itself): an OFFLINE number, labelled as such. (None, None) if absent."""
+    for name in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            return d["all_gemm"]["hbm_bytes_per_launch"], f"profiles/{name} (offline rocprofv3 --pmc passes, commit {d.get('commit', 'n/a')})"
+        except Exception:
+            continue
+    return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--seq", type=int, default=128)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--cpu-baseline-steps", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: every step takes its batch from "
-                    "pinned host memory through the double-buffered DevicePrefetcher (the default keeps inputs resident)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
-                    "the multi-rank code path on a single GPU)")
-    args = ap.parse_args()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
+    if args.print_launch:
+        print(json.dumps([sys.executable, os.path.join(ROOT, "bench.py")] + [a for a in argv if a != "--print-launch"]))
+        return
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -108,20 +176,32 @@ def main():
     dev_index = local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    ranks_seen = 1
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        ones = torch.ones(1, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)  # every rank contributes 1: the collective really spans `world` processes
+        ranks_seen = int(ones.item())
+        if ranks_seen != world or dist.get_world_size() != world:
+            raise SystemExit(f"rank {rank}: all-reduce of ones gave {ranks_seen}, world {world}")
 
     import multimodal_sentiment_aanalysis_amd as mm
     from multimodal_sentiment_aanalysis_amd import _lib
     from multimodal_sentiment_aanalysis_amd.fused import FusedTrainStep
 
     torch.manual_seed(0)
-    model = mm.MultimodalTransformerModel()  # BERT-base + ResNet-50 + fusion head, random init (no checkpoints offline)
+    if args.model == "large":
+        model = mm.MultimodalTransformerModel(bert_config=mm.BERT_LARGE, resnet_config=mm.RESNET101)
+        fwd_gflop = C3_FWD_GFLOP_PER_PAIR
+    else:
+        model = mm.MultimodalTransformerModel()  # BERT-base + ResNet-50 + fusion head, random init (no checkpoints offline)
+        fwd_gflop = FWD_GFLOP_PER_PAIR * (args.seq / 128.0 if args.seq != 128 else 1.0)
+    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "base":
         cpu = cpu_baseline(model, 16, args.cpu_baseline_steps)
     trainer = FusedTrainStep(model, device, precision=args.precision,
                              two_streams=os.environ.get("MMSA_TWO_STREAMS", "0") == "1")  # A/B on one box: 19.23 ms single stream, 19.50 with two
@@ -131,6 +211,16 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def fwd_step(image, ids, mask, labels):
+        # forward of the training graph (batch-statistics BatchNorm, dropout active) without autograd: same kernels as the
+        # forward half of a training step, nothing saved for a backward
+        with torch.no_grad():
+            return model(image, ids, mask, labels)
+
+    step_fn = trainer.step if args.mode == "train" else fwd_step
+    if args.mode == "fwd":
+        model.train()
 
     feed = None
     if args.host_inputs:  # 4 distinct pinned host batches, cycled; copies ride a side stream one step ahead
@@ -154,17 +244,25 @@ def main():
             return iter(DevicePrefetcher(_Cycle(n), device))
 
     for b in (feed(args.warmup) if feed else [batch] * args.warmup):
-        trainer.step(*b)
+        step_fn(*b)
     L = _lib.load()
-    # (1) the timed region: exactly `steps` steps, un-instrumented (HIP events around every GEMM launch cost ~2 ms
-    #     per step, so they are kept out of the throughput number)
-    sync()
-    t0 = time.perf_counter()
-    for b in (feed(args.steps) if feed else [batch] * args.steps):
-        loss, _ = trainer.step(*b)
-    sync()
-    dt = time.perf_counter() - t0
-    # (2) the roofline pass: the same steps again with HIP events on the launch stream around every MFMA GEMM launch
+    # (1) the timed regions: exactly `steps` steps each, un-instrumented, barrier + synchronize on both sides
+    region_s = []
+    loss = None
+    for _ in range(max(1, args.repeats)):
+        sync()
+        t0 = time.perf_counter()
+        for b in (feed(args.steps) if feed else [batch] * args.steps):
+            out = step_fn(*b)
+        sync()
+        region_s.append(time.perf_counter() - t0)
+        loss = out[0] if args.mode == "train" else None
+    el = torch.tensor(region_s, dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)  # max over ranks, region by region
+    region_s = el.tolist()
+    dt = region_s[0]
+    median_s = sorted(region_s)[len(region_s) // 2]
     # (2) the roofline passes, right after the timed steps (skipped under rocprofv3, which times the kernels itself):
     #     (a) HIP events on the launch stream around every MFMA GEMM launch — each launch bracketed in exactly one of
     #         `psteps` steps (index % psteps), because an event pair drains the queue around its kernel;
@@ -175,61 +273,102 @@ def main():
     STAMP_STEPS = 3  # steps averaged by pass (b); MMSA_PROF_DUMP then holds 3 rows per launch of a step
     ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     ms_ev, fl_ev, n_ev = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    fwd = None
     if os.environ.get("MMSA_BENCH_NOPROF", "0") == "0":
         L.mmsa_prof_mode(0)
-        L.mmsa_prof_begin(psteps * 1200)
+        L.mmsa_prof_begin(psteps * 2400)
         sync()
         for ps in range(psteps):
             L.mmsa_prof_sample(psteps, ps)
-            trainer.step(*batch)
+            step_fn(*batch)
         sync()
         L.mmsa_prof_end(ctypes.byref(ms_ev), ctypes.byref(fl_ev), ctypes.byref(n_ev))
         L.mmsa_prof_mode(1)
-        L.mmsa_prof_begin(STAMP_STEPS * 1200)
+        L.mmsa_prof_begin(STAMP_STEPS * 2400)
         sync()
         for _ in range(STAMP_STEPS):
-            trainer.step(*batch)
+            step_fn(*batch)
         sync()
         L.mmsa_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
         L.mmsa_prof_mode(0)
         ms.value /= STAMP_STEPS
         fl.value /= STAMP_STEPS
         n.value //= STAMP_STEPS
-    el = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    dt = el.item()
+        if args.mode == "train":
+            # (3) the forward alone (north_star: ">= 50 % MFMA roofline on the forward at bs=64"): 30 passes of the
+            #     training-mode forward, then its GEMM launches by the kernels' own clock
+            model.train()
+            for _ in range(5):
+                fwd_step(*batch)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                fwd_step(*batch)
+            sync()
+            f_dt = (time.perf_counter() - t0) / 30
+            fms, ffl, fn_ = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+            L.mmsa_prof_mode(1)
+            L.mmsa_prof_begin(STAMP_STEPS * 2400)
+            for _ in range(STAMP_STEPS):
+                fwd_step(*batch)
+            sync()
+            L.mmsa_prof_end(ctypes.byref(fms), ctypes.byref(ffl), ctypes.byref(fn_))
+            L.mmsa_prof_mode(0)
+            f_tf = args.batch * fwd_gflop / f_dt / 1e3
+            g_tf = ffl.value / (fms.value * 1e-3) / 1e12 if fms.value > 0 else 0.0
+            fwd = {"ms": round(f_dt * 1e3, 3), "pairs_per_s_per_gpu": round(args.batch / f_dt, 1),
+                   "algorithmic_tflops": round(f_tf, 2), "frac_of_peak": round(f_tf / peak, 4),
+                   "gemm_tflops": round(g_tf, 2), "gemm_frac_of_peak": round(g_tf / peak, 4),
+                   "gemm_ms": round(fms.value / STAMP_STEPS, 3), "gemm_launches": fn_.value // STAMP_STEPS,
+                   "what": "training-mode forward of the same model and batch, no autograd; 30 passes after the timed steps"}
     if rank == 0:
         pairs = args.batch * world * args.steps
+        flop_mult = 3 if args.mode == "train" else 1
         gemm_tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         gemm_tflops_ev = fl_ev.value / (ms_ev.value * 1e-3) / 1e12 if ms_ev.value > 0 else 0.0
-        step_tflops = pairs * 3 * FWD_GFLOP_PER_PAIR / dt / 1e3 / world
+        step_tflops = pairs * flop_mult * fwd_gflop / dt / 1e3 / world
+        traffic, traffic_src = pmc_traffic()
+        names = {"base": "BERT-base S=%d + ResNet-50 224x224", "large": "BERT-large S=%d + ResNet-101 224x224"}
+        what = ("train step (fwd+CE+bwd+grad all-reduce+clip+AdamW)" if args.mode == "train" else
+                "forward only (training-mode BatchNorm, no autograd)")
+        metric = "(image,text) pairs/sec/node, BERT-base+ResNet50 bs=64/GPU"
+        if args.mode != "train" or args.model != "base":
+            metric = "(image,text) pairs/sec/node, %s, %s, bs=%d/GPU" % (names[args.model] % args.seq, args.mode, args.batch)
         out = {
-            "metric": "(image,text) pairs/sec/node, BERT-base+ResNet50 bs=64/GPU",
+            "metric": metric,
             "value": round(pairs / dt, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic" + (" (host-resident, PCIe-inclusive)" if args.host_inputs else ""),
-            "config": {"workload": "train step (fwd+CE+bwd+grad all-reduce+clip+AdamW): BERT-base S=%d + ResNet-50 224x224 + "
-                                   "MHA fusion head, 3-class CE, random init" % args.seq,
+            "config": {"workload": "%s: %s + MHA fusion head, 3-class CE, random init" % (what, names[args.model] % args.seq),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": args.seq,
-                       "image": "224x224x3", "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
+                       "image": "224x224x3", "parallelism": f"dp{world}", "ranks_seen_by_all_reduce": ranks_seen,
+                       "backend": args.backend if world > 1 else None},
+            "protocol": {"regions": len(region_s), "steps_per_region": args.steps,
+                         "ms_per_step_by_region": [round(s / args.steps * 1e3, 3) for s in region_s],
+                         "median_ms_per_step": round(median_s / args.steps * 1e3, 3),
+                         "median_pairs_per_s": round(pairs / median_s, 2),
+                         "note": "value / ms_per_step = the FIRST region after the warm-up (max over ranks)"},
+            "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(gemm_tflops / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_GEMM_LAUNCH,
-                         "kernel": "gemm2_kernel (+ split-K reducer): every MFMA GEMM launch of 3 steps right after the "
-                                   "timed steps, averaged per step (NT/NN/TN, implicit-GEMM convolutions, grouped weight gradients); duration = "
-                                   "in-kernel clock, first workgroup start to last workgroup end",
+                         "kernel": "every matrix-core GEMM launch (gemm2_kernel + split-K reducer; precision fp32: the "
+                                   "fp32-MFMA kernel) of 3 steps right after the timed steps, averaged per step (NT/NN/TN, "
+                                   "implicit-GEMM convolutions, grouped weight gradients); duration = in-kernel clock, "
+                                   "first workgroup start to last workgroup end",
                          "launches": n.value, "kernel_ms_per_step": round(ms.value, 3),
                          "achieved_hip_events": round(gemm_tflops_ev, 2),
                          "kernel_ms_per_step_hip_events": round(ms_ev.value, 3),
                          "step_algorithmic_tflops_per_gpu": round(step_tflops, 2),
-                         "step_frac_of_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4)},
-            "loss": round(float(loss), 5),
+                         "step_frac_of_peak": round(step_tflops / peak, 4)},
         }
+        if fwd is not None:
+            out["forward"] = fwd
+        if loss is not None:
+            out["loss"] = round(float(loss), 5)
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -221,6 +221,20 @@ size_t mmsa_grad_norm_ws_bytes(void);
 int mmsa_grad_norm(const float* g, int64_t n, float grad_scale, float max_norm, float* norm_out, void* ws, void* stream);
 int mmsa_adamw_step(float* w, const float* g, float* m, float* v, void* w16, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int32_t step, const float* norm_clip, float grad_scale, void* stream);
+/* NaN rule of the reference's step (Trainer.py:74-76 "NaN loss detected, skipping batch": no update): the guarded forms decide
+ * on the device, without a host sync. mmsa_grad_norm (both forms) writes norm_out[1] = -1 when the gradient norm -- or, in
+ * the guarded form, the device scalar *loss (may be NULL) -- is not finite; mmsa_adamw_step (both forms) returns without
+ * touching w, m, v, w16 when norm_clip[1] < 0. *step_count (device int32, may be NULL in the guard) counts the APPLIED steps:
+ * the guard increments it when the step is not skipped, mmsa_adamw_step_dev takes its bias correction from it. */
+int mmsa_grad_norm_guard(const float* g, int64_t n, float grad_scale, float max_norm, const float* loss, int32_t* step_count,
+                         float* norm_out, void* ws, void* stream);
+/* the norm over `nranges` disjoint ranges (host arrays of element offsets / lengths, nranges <= 256) of one gradient buffer:
+ * the trainable sub-ranges of a curriculum phase (dataLoader/MultiTaskTrainer.py:50-177 freezes everything else) */
+int mmsa_grad_norm_ranges(const float* g, const int64_t* offsets, const int64_t* lengths, int32_t nranges, float grad_scale,
+                          float max_norm, const float* loss, int32_t* step_count, float* norm_out, void* ws, void* stream);
+int mmsa_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w16, int64_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, const int32_t* step_count, const float* norm_clip, float grad_scale,
+                        void* stream);
 /* storage cast fp32 -> dtype (refresh of the working weights after a foreign optimizer touched the fp32 master) */
 int mmsa_cast_f32(int32_t dtype, const float* src, void* dst, int64_t n, void* stream);
 

@@ -106,6 +106,25 @@ int mmsa_adamw_step(float* w, const float* g, float* m, float* v, void* w16, int
   if (!w || !g || !m || !v) return MMSA_ERR_ARG;
   return adamw_step(w, g, m, v, w16, n, lr, beta1, beta2, eps, weight_decay, step, norm_clip, grad_scale, (hipStream_t)stream);
 }
+int mmsa_grad_norm_guard(const float* g, int64_t n, float grad_scale, float max_norm, const float* loss, int32_t* step_count,
+                         float* norm_out, void* ws, void* stream) {
+  if (!g || !norm_out || !ws || n <= 0) return MMSA_ERR_ARG;
+  return grad_norm(g, n, grad_scale, max_norm, norm_out, ws, (hipStream_t)stream, loss, step_count);
+}
+int mmsa_grad_norm_ranges(const float* g, const int64_t* offsets, const int64_t* lengths, int32_t nranges, float grad_scale,
+                          float max_norm, const float* loss, int32_t* step_count, float* norm_out, void* ws, void* stream) {
+  if (!g || !offsets || !lengths || !norm_out || !ws) return MMSA_ERR_ARG;
+  static_assert(sizeof(long) == sizeof(int64_t), "LP64");
+  return grad_norm_ranges(g, (const long*)offsets, (const long*)lengths, nranges, grad_scale, max_norm, norm_out, ws,
+                          (hipStream_t)stream, loss, step_count);
+}
+int mmsa_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w16, int64_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, const int32_t* step_count, const float* norm_clip, float grad_scale,
+                        void* stream) {
+  if (!w || !g || !m || !v || !step_count) return MMSA_ERR_ARG;
+  return adamw_step(w, g, m, v, w16, n, lr, beta1, beta2, eps, weight_decay, 0, norm_clip, grad_scale, (hipStream_t)stream,
+                    step_count);
+}
 int mmsa_cast_f32(int32_t dtype, const float* src, void* dst, int64_t n, void* stream) {
   if (!src || !dst) return MMSA_ERR_ARG;
   return cast_f32(dtype, src, dst, n, (hipStream_t)stream);

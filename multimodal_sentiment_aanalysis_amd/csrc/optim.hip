@@ -23,9 +23,13 @@ __global__ __launch_bounds__(256) void grad_sumsq_partial_kernel(const float* __
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-// norm_out[0] = grad_scale * sqrt(sum); norm_out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))
+// norm_out[0] = grad_scale * sqrt(sum); norm_out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)), or -1 = "skip
+// this step" when the norm (or the optional device scalar *loss) is not finite: Trainer.py:74-76 leaves the weights alone
+// on a NaN loss. *step_count (optional) counts the steps that are applied: the AdamW bias correction must not advance on
+// a skipped batch, and the host never learns which ones were skipped (no sync).
 __global__ __launch_bounds__(256) void grad_norm_finalize_kernel(const double* __restrict__ part, int nblk, float grad_scale,
-                                                                 float max_norm, float* __restrict__ norm_out) {
+                                                                 float max_norm, const float* __restrict__ loss,
+                                                                 int* __restrict__ step_count, float* __restrict__ norm_out) {
   // one block, fixed summation tree (a single thread walking the 1024 partials took 57 us)
   __shared__ double red[256];
   double s = 0.0;
@@ -39,16 +43,45 @@ __global__ __launch_bounds__(256) void grad_norm_finalize_kernel(const double* _
   if (threadIdx.x != 0) return;
   const float norm = (float)(sqrt(red[0]) * (double)grad_scale);
   norm_out[0] = norm;
-  norm_out[1] = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+  const bool ok = isfinite(norm) && (!loss || isfinite(*loss));
+  norm_out[1] = !ok ? -1.f : (max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f);
+  if (step_count && ok) *step_count += 1;
 }
 
-size_t grad_norm_ws_bytes() { return SUMSQ_BLOCKS * sizeof(double); }
+size_t grad_norm_ws_bytes() { return 2 * SUMSQ_BLOCKS * sizeof(double); }
 
-int grad_norm(const float* g, long n, float grad_scale, float max_norm, float* norm_out, void* ws, hipStream_t st) {
+// the same norm over several disjoint ranges of one gradient buffer (the trainable sub-ranges of a curriculum phase,
+// dataLoader/MultiTaskTrainer.py:50-177): each range gets a share of the partial blocks, one finalize over all of them
+int grad_norm_ranges(const float* g, const long* offs, const long* lens, int nr, float grad_scale, float max_norm,
+                     float* norm_out, void* ws, hipStream_t st, const float* loss, int* step_count) {
+  if (nr < 1 || nr > 256) return MMSA_ERR_ARG;
+  long total = 0;
+  for (int r = 0; r < nr; ++r) {
+    if (lens[r] <= 0 || offs[r] < 0) return MMSA_ERR_ARG;
+    total += lens[r];
+  }
+  int used = 0;
+  for (int r = 0; r < nr; ++r) {
+    long want = (long)((double)SUMSQ_BLOCKS * (double)lens[r] / (double)total);
+    const long cap = (lens[r] / 4 + 255) / 256 + 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    if (used + want > 2 * SUMSQ_BLOCKS) return MMSA_ERR_ARG;
+    hipLaunchKernelGGL(grad_sumsq_partial_kernel, dim3((int)want), dim3(256), 0, st, g + offs[r], lens[r], (double*)ws + used);
+    used += (int)want;
+  }
+  hipLaunchKernelGGL(grad_norm_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, used, grad_scale, max_norm,
+                     loss, step_count, norm_out);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+int grad_norm(const float* g, long n, float grad_scale, float max_norm, float* norm_out, void* ws, hipStream_t st,
+              const float* loss, int* step_count) {
   const int blocks = (int)min((n / 4 + 255) / 256 + 1, (long)SUMSQ_BLOCKS);
   hipLaunchKernelGGL(grad_sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, g, n, (double*)ws);
   hipLaunchKernelGGL(grad_norm_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, blocks, grad_scale, max_norm,
-                     norm_out);
+                     loss, step_count, norm_out);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
@@ -58,8 +91,16 @@ int grad_norm(const float* g, long n, float grad_scale, float max_norm, float* n
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ w16, long n, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                    const float* __restrict__ norm_clip, float grad_scale) {
-  const float coef = (norm_clip ? norm_clip[1] : 1.f) * grad_scale;
+                                                    const float* __restrict__ norm_clip, float grad_scale,
+                                                    const int* __restrict__ step_count) {
+  const float clip = norm_clip ? norm_clip[1] : 1.f;
+  if (clip < 0.f) return;  // non-finite gradient norm / loss: the step is skipped, w, m, v and the bf16 copy stay as they are
+  if (step_count) {        // bias correction from the device-side count of applied steps (this one included)
+    const float t = (float)*step_count;
+    bc1 = 1.f - powf(b1, t);
+    bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  }
+  const float coef = clip * grad_scale;
   const long n4 = n / 4;
   // every stream is touched once per step (540 MB each: nothing survives in L2 / MALL until its next use), so all
   // fp32 accesses are non-temporal; two independent float4 groups per thread keep 8 loads in flight
@@ -109,13 +150,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
 }
 
 int adamw_step(float* w, const float* g, float* m, float* v, void* w16, long n, float lr, float b1, float b2, float eps,
-               float wd, int step, const float* norm_clip, float grad_scale, hipStream_t st) {
-  if (n <= 0 || step < 1) return MMSA_ERR_ARG;
-  const float bc1 = 1.f - powf(b1, (float)step);
-  const float bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
+               float wd, int step, const float* norm_clip, float grad_scale, hipStream_t st, const int* step_count) {
+  if (n <= 0 || (step < 1 && !step_count)) return MMSA_ERR_ARG;
+  const float bc1 = 1.f - powf(b1, (float)(step < 1 ? 1 : step));
+  const float bc2_sqrt = sqrtf(1.f - powf(b2, (float)(step < 1 ? 1 : step)));
   const int blocks = (int)min((n / 4 + 255) / 256 + 1, 4096L);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, w, g, m, v, (bf16*)w16, n, lr, b1, b2, eps, wd, bc1,
-                     bc2_sqrt, norm_clip, grad_scale);
+                     bc2_sqrt, norm_clip, grad_scale, step_count);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }

@@ -183,8 +183,7 @@ class EngineModule(nn.Module):
         """Refresh the bf16 working copy when the fp32 master changed (torch optimizer step, load_state_dict)."""
         if self.precision != "bf16":
             return self._flat_w
-        token = tuple(self._pmap[n]._version for n, _, _ in (self._specs[0], self._specs[len(self._specs) // 2],
-                                                              self._specs[-1]))
+        token = self._version_token()
         if token != self._wt_token:
             check(_lib.load().mmsa_cast_f32(MMSA_BF16, ptr(self._flat_w), ptr(self._flat_wt), self._numel,
                                             stream_ptr()), "mmsa_cast_f32")
@@ -193,8 +192,12 @@ class EngineModule(nn.Module):
 
     def mark_weights_fresh(self):
         """Called by the fused optimizer, which writes the working copy itself."""
-        self._wt_token = tuple(self._pmap[n]._version for n, _, _ in (self._specs[0], self._specs[len(self._specs) // 2],
-                                                                      self._specs[-1]))
+        self._wt_token = self._version_token()
+
+    def _version_token(self):
+        """Version counters of EVERY parameter (a torch optimizer over a subset, a partial load_state_dict or an in-place
+        edit of one tensor must all refresh the bf16 working copy; ~20 us against a multi-millisecond forward)."""
+        return tuple(p._version for p in self._pmap.values())
 
     # ---- optional side HIP stream ---------------------------------------------------------------------------------
     # The two encoders are independent until the fusion head. With `use_side_stream(True)` this engine enqueues its

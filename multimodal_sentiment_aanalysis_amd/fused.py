@@ -8,6 +8,8 @@
   * global-norm clip + AdamW + bf16 working-copy refresh as two kernels over the flat buffers
     (mmsa_grad_norm, mmsa_adamw_step), the 1/world_size average folded into their grad_scale.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -61,31 +63,59 @@ class GradReducer:
 
 
 class FlatAdamW:
-    """clip_grad_norm_(max_norm) + AdamW over a FlatState's buffers (two kernels): Trainer.py:19-21,80-81."""
+    """clip_grad_norm_(max_norm) + AdamW over a FlatState's buffers (Trainer.py:19-21,80-81) on the HIP kernels.
 
-    def __init__(self, state, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0):
+    `ranges`: [(offset, length)] in elements of the flat buffers — the parameters this optimizer owns (default: all of
+    them). A curriculum phase (dataLoader/MultiTaskTrainer.py) hands over the ranges of its trainable modules: the norm
+    is taken over exactly those, the update touches nothing else. The decision "is this step applied?" is made on the
+    device (Trainer.py:74-76 skips the update on a NaN loss): a non-finite gradient norm or loss leaves w, m, v and the bf16
+    working copy untouched and does not advance the bias-correction step count (a device int32)."""
+
+    def __init__(self, state, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, ranges=None):
         self.state, self.lr, self.wd, self.betas, self.eps, self.max_norm = state, lr, weight_decay, betas, eps, max_norm
         dev = state.flat_w.device
         n = state.flat_w.numel()
+        self.ranges = merge_ranges([(0, n)] if ranges is None else ranges)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.t = 0
+        self.steps = torch.zeros(1, dtype=torch.int32, device=dev)  # applied (not skipped) steps
         self.norm_ws = torch.empty(_lib.load().mmsa_grad_norm_ws_bytes(), dtype=torch.uint8, device=dev)
-        self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)  # [total norm, clip coefficient]
+        self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)  # [total norm, clip coefficient | -1 = skipped]
+        self._offs = (ctypes.c_int64 * len(self.ranges))(*[a for a, _ in self.ranges])
+        self._lens = (ctypes.c_int64 * len(self.ranges))(*[n_ for _, n_ in self.ranges])
 
-    def step(self, grad_scale=1.0):
+    @property
+    def t(self):
+        """Number of applied steps (host read: a sync; for tests and checkpoints only)."""
+        return int(self.steps.item())
+
+    def step(self, grad_scale=1.0, loss=None):
         L = _lib.load()
         st = self.state
-        n = st.flat_w.numel()
-        check(L.mmsa_grad_norm(ptr(st.flat_g), n, grad_scale, self.max_norm, ptr(self.norm_out), ptr(self.norm_ws),
-                               stream_ptr()), "mmsa_grad_norm")
-        self.t += 1
-        check(L.mmsa_adamw_step(ptr(st.flat_w), ptr(st.flat_g), ptr(self.m), ptr(self.v), ptr(st.flat_wt), n, self.lr,
-                                self.betas[0], self.betas[1], self.eps, self.wd, self.t, ptr(self.norm_out), grad_scale,
-                                stream_ptr()), "mmsa_adamw_step")
+        check(L.mmsa_grad_norm_ranges(ptr(st.flat_g), self._offs, self._lens, len(self.ranges), grad_scale, self.max_norm,
+                                      ptr(loss), ptr(self.steps), ptr(self.norm_out), ptr(self.norm_ws), stream_ptr()),
+              "mmsa_grad_norm_ranges")
+        for a, n in self.ranges:
+            w16 = None if st.flat_wt is None else st.flat_wt[a:a + n]
+            check(L.mmsa_adamw_step_dev(ptr(st.flat_w[a:a + n]), ptr(st.flat_g[a:a + n]), ptr(self.m[a:a + n]),
+                                        ptr(self.v[a:a + n]), ptr(w16), n, self.lr, self.betas[0], self.betas[1], self.eps,
+                                        self.wd, ptr(self.steps), ptr(self.norm_out), grad_scale, stream_ptr()),
+                  "mmsa_adamw_step_dev")
         for e, _, _ in st.ranges:
             if not isinstance(e, HeadEngine):
                 e.mark_weights_fresh()
+
+
+def merge_ranges(ranges):
+    """Sort and coalesce [(offset, length)] (touching ranges become one: fewer launches, larger collectives)."""
+    out = []
+    for a, n in sorted((int(a), int(n)) for a, n in ranges if n > 0):
+        if out and out[-1][0] + out[-1][1] >= a:
+            end = max(out[-1][0] + out[-1][1], a + n)
+            out[-1] = (out[-1][0], end - out[-1][0])
+        else:
+            out.append((a, n))
+    return out
 
 
 class FusedTrainStep:
@@ -134,7 +164,9 @@ class FusedTrainStep:
             self._image_net.join()
         if self.reducer is not None:
             self.reducer.finish()
-        self.opt.step(1.0 / self.world)
+        # NaN rule (Trainer.py:74-76): decided on the device from the reduced gradient norm (identical on every rank, so
+        # the replicas stay in step); a NaN loss on any rank makes its gradients, hence the reduced norm, non-finite
+        self.opt.step(1.0 / self.world, self.loss if self.world == 1 else None)
         return self.loss, logits
 
     @property

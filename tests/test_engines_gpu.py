@@ -471,3 +471,90 @@ def test_c3_bert_large_resnet101_train_steps(dev):
     assert losses[-1] < losses[0], losses
     del step, model
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------ step tail rules
+def _mini_step(dev, precision="bf16"):
+    from multimodal_sentiment_aanalysis_amd.fused import FusedTrainStep
+    torch.manual_seed(0)
+    model = mm.MultimodalTransformerModel(bert_config=MINI_BERT, resnet_config=MINI_RESNET, dropout=0.0)
+    step = FusedTrainStep(model, dev, precision=precision)
+    image, ids, mask, labels = synth_batch(8, 32, 64, 64, MINI_BERT["vocab"], seed=3)
+    return step, (image.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
+
+
+def test_fused_step_skips_non_finite_batch(dev):
+    """Trainer.py:74-76: a NaN loss skips the update. The fused step decides on the device (no host sync): a batch whose
+    loss / gradient norm is not finite must leave the weights, both AdamW moments, the bf16 working copy and the
+    bias-correction step count exactly as they were, and the next good batch must train on as if nothing happened."""
+    step, batch = _mini_step(dev)
+    st, opt = step.state, step.opt
+    loss0, _ = step.step(*batch)
+    assert torch.isfinite(loss0) and opt.t == 1
+    snap = [t.clone() for t in (st.flat_w, st.flat_wt, opt.m, opt.v)]
+    bad = batch[0].clone()
+    bad[1, 0, 5, 7] = float("inf")
+    loss_bad, _ = step.step(bad, *batch[1:])
+    assert not torch.isfinite(loss_bad)
+    assert float(opt.norm_out[1]) == -1.0, "skip flag"
+    for a, b, nm in zip((st.flat_w, st.flat_wt, opt.m, opt.v), snap, ("w", "bf16 copy", "m", "v")):
+        assert torch.equal(a, b), f"{nm} changed on a skipped step"
+    assert opt.t == 1, "bias-correction step count advanced on a skipped step"
+    loss1, _ = step.step(*batch)
+    assert torch.isfinite(loss1) and opt.t == 2
+    assert torch.isfinite(st.flat_w).all() and not torch.equal(st.flat_w, snap[0])
+    # the same two good steps without the bad batch in between give the same weights (BN running buffers aside, which the
+    # forward of the skipped batch did touch — as the reference's forward does before its NaN check)
+    step_b, _ = _mini_step(dev)
+    step_b.step(*batch)
+    step_b.step(*batch)
+    assert float(loss1) == pytest.approx(float(step_b.loss), rel=1e-4)
+
+
+def test_flat_adamw_over_sub_ranges(dev):
+    """FlatAdamW(ranges=...) — a curriculum phase's optimizer (MultiTaskTrainer.py:50-177) — takes the clip norm over its
+    ranges only and updates nothing outside them; against torch.optim.AdamW + clip_grad_norm_ over the same parameters."""
+    from multimodal_sentiment_aanalysis_amd.fused import FlatAdamW
+    torch.manual_seed(0)
+    model = mm.MultimodalTransformerModel(bert_config=MINI_BERT, resnet_config=MINI_RESNET, dropout=0.0, multitask=True)
+    state = materialize(model, dev, "fp32")
+    state.flat_g.copy_(torch.randn_like(state.flat_g) * 0.01)
+    # the valence head's parameters (phase 3 of the reference optimizes exactly these)
+    sub = [(n, p) for n, p in model.named_parameters() if n.startswith("valence_head.")]
+    base = state.flat_w.data_ptr()
+    ranges = [((p.data_ptr() - base) // 4, p.numel()) for _, p in sub]
+    ref_p = [torch.nn.Parameter(p.detach().clone()) for _, p in sub]
+    for rp, (_, p) in zip(ref_p, sub):
+        rp.grad = p.grad.detach().clone()
+    ref_opt = torch.optim.AdamW(ref_p, lr=1e-3, weight_decay=1e-4)
+    w_before = state.flat_w.clone()
+    opt = FlatAdamW(state, lr=1e-3, weight_decay=1e-4, max_norm=1.0, ranges=ranges)
+    for _ in range(3):
+        total = torch.nn.utils.clip_grad_norm_(ref_p, 1.0)
+        ref_opt.step()
+        for rp, (_, p) in zip(ref_p, sub):  # clip_grad_norm_ scaled the reference's grads in place: restore for the next round
+            rp.grad = p.grad.detach().clone()
+        opt.step()
+        assert float(opt.norm_out[0]) == pytest.approx(float(total), rel=1e-5)
+    for rp, (n, p) in zip(ref_p, sub):
+        assert rel_err(p, rp) < 1e-5, n
+    touched = torch.zeros_like(state.flat_w, dtype=torch.bool)
+    for a, n in opt.ranges:
+        touched[a:a + n] = True
+    assert torch.equal(state.flat_w[~touched], w_before[~touched]), "parameters outside the optimizer's ranges moved"
+
+
+def test_working_copy_follows_any_parameter_edit(dev):
+    """The bf16 working copy must be refreshed when ANY parameter of an engine changes (an optimizer over a few layers,
+    a partial load_state_dict, an in-place edit): round 1 watched three tensors only."""
+    torch.manual_seed(0)
+    net = BertTextNet(MINI_BERT)
+    net.precision = "bf16"
+    net.to(dev)
+    _, ids, mask, _ = synth_batch(2, 32, 32, 32, MINI_BERT["vocab"], seed=5)
+    with torch.no_grad():
+        a = net(ids.to(dev), mask.to(dev)).clone()
+        p = dict(net.named_parameters())["bert.encoder.layer.1.attention.output.dense.weight"]  # neither first, middle nor last
+        p.mul_(1.5)
+        b = net(ids.to(dev), mask.to(dev)).clone()
+    assert not torch.equal(a, b), "stale bf16 working copy after an in-place edit of one mid-layer tensor"
