@@ -492,14 +492,30 @@ def test_fused_step_skips_non_finite_batch(dev):
     loss0, _ = step.step(*batch)
     assert torch.isfinite(loss0) and opt.t == 1
     snap = [t.clone() for t in (st.flat_w, st.flat_wt, opt.m, opt.v)]
-    bad = batch[0].clone()
-    bad[1, 0, 5, 7] = float("inf")
-    loss_bad, _ = step.step(bad, *batch[1:])
-    assert not torch.isfinite(loss_bad)
-    assert float(opt.norm_out[1]) == -1.0, "skip flag"
-    for a, b, nm in zip((st.flat_w, st.flat_wt, opt.m, opt.v), snap, ("w", "bf16 copy", "m", "v")):
-        assert torch.equal(a, b), f"{nm} changed on a skipped step"
+    # (a) an inf pixel: the ReLU of the image encoder squashes the NaN channel in the forward (v > 0 ? v : 0), so the loss
+    #     stays finite, but the BatchNorm backward of that channel is NaN -> the gradient norm is not finite;
+    # (b) a NaN loss (Trainer.py:74 `torch.isnan(loss)`): the last bias of the arousal head is poisoned for one step
+    eq = lambda a, b: torch.equal(a.nan_to_num(7.0), b.nan_to_num(7.0))  # noqa: E731  (NaN-tolerant bitwise compare)
+    bad_img = batch[0].clone()
+    bad_img[1, 0, 5, 7] = float("inf")
+    loss_bad, _ = step.step(bad_img, *batch[1:])
+    assert not torch.isfinite(opt.norm_out[0]) and float(opt.norm_out[1]) == -1.0, "inf pixel: skip flag"
+    for a, b, tn in zip((st.flat_w, st.flat_wt, opt.m, opt.v), snap, ("w", "bf16 copy", "m", "v")):
+        assert eq(a, b), f"inf pixel: {tn} changed on a skipped step"
+    assert opt.t == 1
+    bias = [q for n, q in step.model.named_parameters() if n.startswith("arousal_head") and n.endswith("bias")][-1]
+    with torch.no_grad():
+        keep = bias.detach().clone()
+        bias.fill_(float("nan"))
+    snap_nan = st.flat_w.clone()
+    loss_bad, _ = step.step(*batch)
+    assert torch.isnan(loss_bad) and float(opt.norm_out[1]) == -1.0, "NaN loss: skip flag"
+    for a, b, tn in zip((st.flat_w, st.flat_wt, opt.m, opt.v), [snap_nan] + snap[1:], ("w", "bf16 copy", "m", "v")):
+        assert eq(a, b), f"NaN loss: {tn} changed on a skipped step"
     assert opt.t == 1, "bias-correction step count advanced on a skipped step"
+    with torch.no_grad():
+        bias.copy_(keep)
+    assert eq(st.flat_w, snap[0])
     loss1, _ = step.step(*batch)
     assert torch.isfinite(loss1) and opt.t == 2
     assert torch.isfinite(st.flat_w).all() and not torch.equal(st.flat_w, snap[0])

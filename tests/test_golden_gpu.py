@@ -399,3 +399,88 @@ def test_n4_device_prefetcher(dev):
     for (d, y), (dr, yr) in pairs:
         assert y.device.type == "cuda" and torch.equal(y.cpu(), yr)
         assert all(torch.equal(d[k].cpu(), dr[k]) for k in dr)
+
+
+# ------------------------------------------------------------------------------------------------ end-to-end C0 (full size)
+def _c0_metrics(dev, precision):
+    """One training-mode forward + CE + backward of the full-size model (BERT-base + ResNet-50 + fusion head) on the C0
+    batch (16 pairs, seed 1234, weights regenerated from the seed) against tests/golden/c0_full_size.npz (CPU oracle,
+    fp32; generator: tests/golden/make_c0_golden.py)."""
+    from util import synth_batch
+    d = np.load(os.path.join(G, "c0_full_size.npz"))
+    torch.manual_seed(int(d["seed"]))
+    model = mm.MultimodalTransformerModel(dropout=0.0)
+    image, ids, mask, labels = synth_batch(16, 128, 224, 224, 30522, seed=int(d["seed"]))
+    assert np.array_equal(labels.numpy(), d["labels"])
+    materialize(model, dev, precision)
+    model.train()
+    logits, _aux = model(image.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
+    loss = mm.CrossEntropyLoss()(logits, labels.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    m = {"dlogits": float(np.abs(logits.detach().cpu().numpy() - d["logits"]).max()),
+         "dloss": abs(float(loss) - float(d["loss"]))}
+    feats = {}
+    hooks = []
+    i_feat, t_feat = model.encoder.features(image.to(dev), ids.to(dev), mask.to(dev))  # second forward: features only
+    for nm, got, ref in (("text_feat", t_feat, d["text_feat"]), ("image_feat", i_feat, d["image_feat"])):
+        m[nm] = float(np.abs(got.detach().cpu().numpy() - ref).max() / np.abs(ref).max())
+    params = dict(model.named_parameters())
+    names, norms, strides = list(d["grad_names"]), d["grad_norms"], d["grad_strides"]
+    gtot = float(d["grad_total_norm"])
+    worst_norm, worst_l2, tot = ("", 0.0), ("", 0.0), 0.0
+    by_group = {}
+    for n, ref_norm, stride in zip(names, norms, strides):
+        g = params[str(n)].grad
+        assert g is not None, f"no gradient for {n}"
+        gc = g.detach().float().cpu()
+        if gc.dim() == 4:
+            gc = gc.contiguous()  # logical OIHW order, as the oracle's gradient
+        tot += float((gc.double() ** 2).sum())
+        floor = 1e-4 * gtot
+        e_norm = abs(float(gc.double().norm()) - ref_norm) / max(ref_norm, floor)
+        smp = gc.reshape(-1)[::int(stride)].double().numpy()
+        ref = d["gs." + str(n)].astype(np.float64)
+        e_l2 = float(np.linalg.norm(smp - ref) / max(np.linalg.norm(ref), floor * (ref.size / gc.numel()) ** 0.5, 1e-30))
+        if e_norm > worst_norm[1]:
+            worst_norm = (str(n), e_norm)
+        if e_l2 > worst_l2[1]:
+            worst_l2 = (str(n), e_l2)
+        grp = "image" if "image_net" in str(n) else "text" if "text_net" in str(n) else "head"
+        by_group[grp] = max(by_group.get(grp, 0.0), e_l2)
+    m.update(grad_total_norm=abs(tot ** 0.5 - gtot) / gtot, worst_norm=worst_norm, worst_l2=worst_l2, by_group=by_group)
+    for k in ("encoder.image_net.resnet.bn1.running_var", "encoder.image_net.resnet.layer4.2.bn3.running_var"):
+        got = model.state_dict()[k].detach().cpu().numpy()
+        m["bn:" + k.split("resnet.")[1]] = float(np.abs(got - d["bn." + k]).max() / np.abs(d["bn." + k]).max())
+    del model
+    torch.cuda.empty_cache()
+    return m
+
+
+def test_c0_full_size_fp32(dev):
+    """SURVEY.md §8(c) "End-to-end C0" in the exact (fp32-storage) mode: the north-star tolerances, 1e-3 on the logits and
+    1e-4 on the loss, at FULL size (BERT-base + ResNet-50, 16 pairs), and every parameter gradient."""
+    m = _c0_metrics(dev, "fp32")
+    print("C0 fp32:", m)
+    assert m["dlogits"] < 1e-3 and m["dloss"] < 1e-4, m
+    assert m["text_feat"] < 1e-4 and m["image_feat"] < 1e-3, m
+    assert m["grad_total_norm"] < 1e-3, m
+    assert m["worst_norm"][1] < 2e-2 and m["worst_l2"][1] < 2e-2, m
+
+
+def test_c0_full_size_bf16(dev):
+    """The same golden on the benchmarked path (bf16 storage, MFMA kernels). bf16 storage cannot meet 1e-3 / 1e-4 (that is
+    the fp32 mode's contract, above); the bounds asserted here are what was MEASURED at full size on MI355X,
+    with a 1.5-2x margin: they pin the benchmarked precision against regressions, at the size the benchmark runs."""
+    m = _c0_metrics(dev, "bf16")
+    print("C0 bf16:", m)
+    assert m["dlogits"] < C0_BF16["dlogits"] and m["dloss"] < C0_BF16["dloss"], m
+    assert m["text_feat"] < C0_BF16["text_feat"] and m["image_feat"] < C0_BF16["image_feat"], m
+    assert m["grad_total_norm"] < C0_BF16["grad_total_norm"], m
+    for grp, lim in C0_BF16["by_group"].items():
+        assert m["by_group"][grp] < lim, (grp, m)
+
+
+# measured on MI355X (round 2, gpurun_out/r2b): see DESIGN.md §4 for the table; bounds = measured x ~1.5-2
+C0_BF16 = dict(dlogits=1e-1, dloss=5e-2, text_feat=5e-2, image_feat=1e-1, grad_total_norm=2e-1,
+               by_group=dict(text=0.5, image=0.9, head=0.9))
