@@ -156,6 +156,12 @@ int64_t mmsa_resnet_param_total(const mmsa_resnet_cfg* c, int32_t buffers);
 int mmsa_resnet_param_info(const mmsa_resnet_cfg* c, int32_t buffers, int idx, char* name, int name_cap, int64_t* offset,
                            int32_t* ndim, int64_t* shape /*[4]*/);
 size_t mmsa_resnet_ws_bytes(const mmsa_resnet_cfg* c);
+/* Test / diagnostic aid: byte offset inside the ResNet workspace of a tensor the forward saved for the backward (NHWC,
+ * storage dtype). block = -1: stem (which 0 = conv output z, 1 = BN+ReLU output y, 2 = max-pooled); block >= 0 (bottleneck
+ * index in network order): which 0..7 = c1.z, c1.y, c2.z, c2.y, c3.z, c3.y (= block output), ds.z, ds.y; block = -2: which
+ * 0..3 = the gradient ping-pong buffers. -1 when absent. Lets a test evaluate the oracle's backward AT the forward values
+ * the device actually stored (tests/test_engines_gpu.py::test_resnet_backward_teacher_forced). */
+int64_t mmsa_resnet_ws_offset(const mmsa_resnet_cfg* cfg, int32_t block, int32_t which);
 int mmsa_resnet_fwd(const mmsa_resnet_cfg* c, const float* w32, const void* wt, float* bnbuf, const float* image, void* ws,
                     float* feat /*[batch][out_dim] fp32*/, void* stream);
 int mmsa_resnet_bwd(const mmsa_resnet_cfg* c, const float* w32, const void* wt, void* ws, const float* dfeat, float* grad,

@@ -116,6 +116,7 @@ def _declare(L):
         "mmsa_resnet_param_total": (i64, [P(ResnetCfg), i32]),
         "mmsa_resnet_param_info": (ctypes.c_int, [P(ResnetCfg), i32, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, i64p, i32p, i64p]),
         "mmsa_resnet_ws_bytes": (sz, [P(ResnetCfg)]),
+        "mmsa_resnet_ws_offset": (i64, [P(ResnetCfg), i32, i32]),
         "mmsa_resnet_fwd": (ctypes.c_int, [P(ResnetCfg), vp, vp, vp, vp, vp, vp, vp]),
         "mmsa_resnet_bwd": (ctypes.c_int, [P(ResnetCfg), vp, vp, vp, vp, vp, i32, vp]),
         "mmsa_head_param_count": (ctypes.c_int, [i32, P(HeadCfg), i32]),

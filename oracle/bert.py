@@ -25,11 +25,11 @@ def _ln(x, w, b, eps):
 def bert_forward(sd, p, input_ids, attention_mask, cfg, pol=FP32):
     """Returns (last_hidden [B,S,H], pooled [B,H]). `p` is the name prefix of the BertModel parameters (HF names).
     `pol.q` marks where the bf16 HIP path stores a rounded tensor."""
-    q = pol.q
+    q, qw = pol.q, pol.qw
     B, S = input_ids.shape
     H, A, eps = cfg["hidden"], cfg["heads"], cfg["ln_eps"]
     hd = H // A
-    W = lambda n: q(sd[p + n])  # working copy of a matrix parameter in the storage type
+    W = lambda n: qw(sd[p + n])  # working copy of a matrix parameter in the storage type (its gradient stays fp32)
     emb = (W("embeddings.word_embeddings.weight")[input_ids]
            + W("embeddings.position_embeddings.weight")[torch.arange(S)].unsqueeze(0)
            + W("embeddings.token_type_embeddings.weight")[0].view(1, 1, H))

@@ -20,9 +20,9 @@ def encoder_features(sd, image, token_ids, attention_mask, cfg, training, pol=FP
     """text/image features [B,256] (fp32): the two encoder-slot outputs."""
     ids = token_ids.long()
     _, pooled = bert_forward(sd, prefix + "text_net.bert.", ids, attention_mask, cfg["bert"], pol)
-    t = pooled @ pol.q(sd[prefix + "text_net.proj.weight"]).t() + sd[prefix + "text_net.proj.bias"]
+    t = pooled @ pol.qw(sd[prefix + "text_net.proj.weight"]).t() + sd[prefix + "text_net.proj.bias"]
     feat = resnet_forward(sd, prefix + "image_net.resnet.", image.float(), cfg["resnet"], training, pol)
-    i = feat @ pol.q(sd[prefix + "image_net.proj.weight"]).t() + sd[prefix + "image_net.proj.bias"]
+    i = feat @ pol.qw(sd[prefix + "image_net.proj.weight"]).t() + sd[prefix + "image_net.proj.bias"]
     return t, i
 
 

@@ -57,28 +57,31 @@ def _bn(sd, p, x, training, pol, eps=1e-5, momentum=0.1):
 
 
 def resnet_forward(sd, p, image, cfg, training, pol=FP32, trace=None):
-    """image [B,3,H,W] fp32 -> pooled features [B, 512*expansion]. `trace` (dict) collects per-conv tensors for tests."""
-    q = pol.q
-    conv = lambda x, n, s, pad: q(F.conv2d(x, q(sd[p + n]), stride=s, padding=pad))
-    x = q(image)
-    x = q(torch.relu(_bn(sd, p + "bn1", conv(x, "conv1.weight", 2, 3), training, pol)))
+    """image [B,3,H,W] fp32 -> pooled features [B, 512*expansion]. `trace` (dict) collects per-conv tensors for tests.
+    Every stored activation is a named rounding point of the policy (names: stem.z, stem.y, layer{s}.{b}.{c1,c2,c3,ds}.{z,y},
+    pooled; c3.y is the block output) — the tensors the HIP engine keeps in its workspace (resnet_engine.hip ConvWs)."""
+    q, qw = pol.q, pol.qw
+    conv = lambda x, n, s, pad, nm: q(F.conv2d(x, qw(sd[p + n]), stride=s, padding=pad), nm)
+    x = q(image, "image")
+    x = q(torch.relu(_bn(sd, p + "bn1", conv(x, "conv1.weight", 2, 3, "stem.z"), training, pol)), "stem.y")
     x = F.max_pool2d(x, 3, 2, 1)
     for si, nb in enumerate(cfg["blocks"]):
         for b in range(nb):
-            bp = f"{p}layer{si + 1}.{b}."
+            L = f"layer{si + 1}.{b}."
+            bp = p + L
             stride = 2 if (b == 0 and si > 0) else 1
             idn = x
-            z1 = conv(x, f"layer{si + 1}.{b}.conv1.weight", 1, 0)
-            y1 = q(torch.relu(_bn(sd, bp + "bn1", z1, training, pol)))
+            z1 = conv(x, L + "conv1.weight", 1, 0, L + "c1.z")
+            y1 = q(torch.relu(_bn(sd, bp + "bn1", z1, training, pol)), L + "c1.y")
             if trace is not None:
                 for nm, t in (("c1.z", z1), ("c1.y", y1)):
                     if t.requires_grad:
                         t.retain_grad()
-                    trace[f"layer{si + 1}.{b}.{nm}"] = t
-            y = q(torch.relu(_bn(sd, bp + "bn2", conv(y1, f"layer{si + 1}.{b}.conv2.weight", stride, 1), training, pol)))
-            z = _bn(sd, bp + "bn3", conv(y, f"layer{si + 1}.{b}.conv3.weight", 1, 0), training, pol)
+                    trace[L + nm] = t
+            y = q(torch.relu(_bn(sd, bp + "bn2", conv(y1, L + "conv2.weight", stride, 1, L + "c2.z"), training, pol)), L + "c2.y")
+            z = _bn(sd, bp + "bn3", conv(y, L + "conv3.weight", 1, 0, L + "c3.z"), training, pol)
             if b == 0:
-                idn = q(_bn(sd, bp + "downsample.1", conv(x, f"layer{si + 1}.{b}.downsample.0.weight", stride, 0),
-                            training, pol))
-            x = q(torch.relu(z + idn))
-    return q(x.mean((2, 3)))
+                idn = q(_bn(sd, bp + "downsample.1", conv(x, L + "downsample.0.weight", stride, 0, L + "ds.z"), training, pol),
+                        L + "ds.y")
+            x = q(torch.relu(z + idn), L + "c3.y")
+    return q(x.mean((2, 3)), "pooled")
