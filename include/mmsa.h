@@ -35,9 +35,12 @@ extern "C" {
 #define MMSA_BF16 1
 
 /* GEMM implementation selector */
-#define MMSA_GEMM_F32_SIMT 0  /* fp32 storage, VALU fma (exact-fp32 mode, fusion head) */
+#define MMSA_GEMM_F32_SIMT 0  /* fp32 storage: the exact-fp32 mode as the engines run it — the fp32-MFMA kernel when the problem is
+                                 large enough for its 128x128 tile, else the VALU-fma kernel (fusion head, 3-class heads) */
 #define MMSA_GEMM_BF16_MFMA 1 /* bf16 storage, v_mfma_f32_16x16x32_bf16 */
 #define MMSA_GEMM_BF16_SIMT 2 /* bf16 storage, VALU fma (on-device cross-check of the MFMA kernel) */
+#define MMSA_GEMM_F32_MFMA 3  /* fp32 storage, v_mfma_f32_32x32x2_f32 forced (any size): bitwise equal to impl 4 */
+#define MMSA_GEMM_F32_VALU 4  /* fp32 storage, VALU fma forced (the checker of impl 3) */
 
 #define MMSA_ACT_NONE 0
 #define MMSA_ACT_GELU 1 /* exact erf GELU: nn.GELU() at MultimodalModel.py:173,182,187,195 */
@@ -112,7 +115,7 @@ int mmsa_colsum(int32_t dtype, const void* x, int64_t ldx, float* out, int32_t a
                 int32_t N, void* stream);
 
 /* ---- BERT self-attention core, head_dim 64: softmax(QK^T/8 + mask)V on the packed QKV projection ------------
- * impl as MMSA_GEMM_* (0 fp32 SIMT, 1 bf16 MFMA, 2 bf16 SIMT). qkv [B*S][3*heads*64], ctx [B*S][heads*64],
+ * impl as MMSA_GEMM_* (0 fp32 SIMT, 1 bf16 MFMA, 2 bf16 SIMT; attention has no 3 / 4). qkv [B*S][3*heads*64], ctx [B*S][heads*64],
  * mask [B][S] fp32 (1 keep / 0 masked) or NULL. Backward writes d_qkv packed like qkv. */
 size_t mmsa_attention_bwd_ws_bytes(int32_t B, int32_t S, int32_t heads);
 int mmsa_attention_fwd(int32_t impl, const void* qkv, const float* mask, void* ctx, int32_t B, int32_t S, int32_t heads,

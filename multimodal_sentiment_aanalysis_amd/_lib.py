@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmsa_hip.so")
 
 MMSA_F32, MMSA_BF16 = 0, 1
-GEMM_F32_SIMT, GEMM_BF16_MFMA, GEMM_BF16_SIMT = 0, 1, 2
+GEMM_F32_SIMT, GEMM_BF16_MFMA, GEMM_BF16_SIMT, GEMM_F32_MFMA, GEMM_F32_VALU = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 
 _STATUS = {1: "bad argument", 2: "kernel launch failure", 3: "unsupported shape"}

@@ -49,6 +49,8 @@ int mmsa_gemm(const mmsa_gemm_desc* d, int32_t impl, void* stream) {
     case MMSA_GEMM_F32_SIMT: return gemm_f32_launch(p, st);
     case MMSA_GEMM_BF16_MFMA: return gemm_bf16_launch(p, st);
     case MMSA_GEMM_BF16_SIMT: return gemm_bf16_simt_launch(p, st);
+    case MMSA_GEMM_F32_MFMA: return p.c_gw > 0 ? MMSA_ERR_UNSUPPORTED : gemm_f32_mfma_launch(p, st);
+    case MMSA_GEMM_F32_VALU: return gemm_f32_valu_launch(p, st);
     default: return MMSA_ERR_ARG;
   }
 }

@@ -93,5 +93,13 @@ extern int g2_last_plan[3];
 int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st);
 int gemm_bf16_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st);  // + roofline record
 int gemm_f32_launch(const GemmParams& p, hipStream_t st);
+// exact-fp32 GEMM on the matrix cores (gemm_f32_mfma.hip); gemm_f32_launch routes eligible problems to it
+bool gemm_f32_mfma_eligible(const GemmParams& p);
+int gemm_f32_valu_launch(const GemmParams& p, hipStream_t st);  // the VALU-fma kernel, unconditionally
+int gemm_f32_mfma_launch(const GemmParams& p, hipStream_t st);
+// roofline record of one matrix-core launch made outside gemm_mfma.hip: open returns a slot (or -1: not recording) and sets
+// p.stamp / records the start event; close records the end event
+int gemm_prof_open(GemmParams& p, hipStream_t st);
+void gemm_prof_close(int slot, hipStream_t st);
 size_t gemm_splitk_ws_bytes(int M, int N, int split_k);
 const void* mmsa_zero_page();

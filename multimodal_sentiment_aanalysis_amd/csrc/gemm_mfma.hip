@@ -471,6 +471,22 @@ int gemm_prof_end(double* total_ms, double* total_flop, long* launches) {
 
 static int gemm_bf16_launch_inner(const GemmParams& pin, hipStream_t st);
 
+int gemm_prof_open(GemmParams& p, hipStream_t st) {
+  if (!g_prof_on || g_prof_used >= g_prof.size() || !prof_take()) return -1;
+  const int slot = (int)g_prof_used++;
+  ProfRec& r = g_prof[slot];
+  r.flop = 2.0 * p.M * p.N * (double)p.K;
+  r.M = p.M; r.N = p.N; r.K = p.K; r.akm = p.a_kmajor; r.bkm = p.b_kmajor; r.gather = p.gather; r.split = p.split_k;
+  r.epi = (p.mul || p.add) ? 2 : (p.bias || p.C2 || p.act != MMSA_ACT_NONE) ? 1 : 0;
+  r.wm = 2; r.nj = 2; r.ksplit = p.split_k;
+  if (g_prof_mode == 1) p.stamp = g_stamp_dev + 2 * slot;
+  else (void)hipEventRecord(r.a, st);
+  return slot;
+}
+void gemm_prof_close(int slot, hipStream_t st) {
+  if (slot >= 0 && g_prof_mode == 0) (void)hipEventRecord(g_prof[slot].b, st);
+}
+
 int gemm_bf16_launch(const GemmParams& pin, hipStream_t st) {
   if (!g_prof_on || g_prof_used >= g_prof.size() || !prof_take()) return gemm_bf16_launch_inner(pin, st);
   ProfRec& r = g_prof[g_prof_used];

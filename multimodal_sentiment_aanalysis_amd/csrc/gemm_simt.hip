@@ -7,55 +7,12 @@
 // (every gather mode of gemm.h), which is what makes it a useful checker; it is not a performance kernel.
 #include "gemm.h"
 #include "gemm_epilogue.h"
+#include "gemm_generic.h"
 #include <type_traits>
 
 #define SBM 64
 #define SBN 64
 #define SBK 32
-
-__device__ __forceinline__ long simt_tap_src(const ConvGeom& g, int pix, int ky, int kx) {
-  const int ghw = g.GH * g.GW;
-  const int img = pix / ghw, rem = pix - img * ghw;
-  const int y = rem / g.GW, x = rem - y * g.GW;
-  int sy = y * g.mul + g.off + ky * g.kmul, sx = x * g.mul + g.offx + kx * g.kmul;
-  if (g.div > 1) {
-    if (sy < 0 || sx < 0 || sy % g.div || sx % g.div) return -1;
-    sy /= g.div; sx /= g.div;
-  }
-  if (sy < 0 || sx < 0 || sy >= g.SH || sx >= g.SW) return -1;
-  return (((long)img * g.SH + sy) * g.SW + sx) * g.src_pix_stride;
-}
-
-template <typename T>
-__device__ __forceinline__ float simt_load_a(const GemmParams& p, int m, int k, int kend) {
-  if (m >= p.M || k >= kend) return 0.f;
-  const T* A = (const T*)p.A;
-  if (p.gather == 1) {
-    const int tap = k / p.g.cper, c = k - tap * p.g.cper;
-    const int ky = tap / p.g.KW, kx = tap - ky * p.g.KW;
-    const long s = simt_tap_src(p.g, m, ky, kx);
-    return s < 0 ? 0.f : to_f32<T>(A[s + c]);
-  }
-  return to_f32<T>(p.a_kmajor ? A[(long)k * p.lda + m] : A[(long)m * p.lda + k]);
-}
-
-template <typename T>
-__device__ __forceinline__ float simt_load_b(const GemmParams& p, int k, int n, int kend) {
-  if (n >= p.N || k >= kend) return 0.f;
-  const T* B = (const T*)p.B;
-  if (p.gather == 2) {
-    const int tap = n / p.g.cper, c = n - tap * p.g.cper;
-    const int ky = tap / p.g.KW, kx = tap - ky * p.g.KW;
-    const long s = simt_tap_src(p.g, k, ky, kx);
-    return s < 0 ? 0.f : to_f32<T>(B[s + c]);
-  }
-  if (p.gather == 1 && p.b_kmajor) {
-    const int tap = k / p.g.cper, c = k - tap * p.g.cper;
-    const int ky = tap / p.g.KW, kx = tap - ky * p.g.KW;
-    return to_f32<T>(B[(long)c * p.ldb + b_tap_offset(p, ky, kx) + n]);
-  }
-  return to_f32<T>(p.b_kmajor ? B[(long)k * p.ldb + n] : B[(long)n * p.ldb + k]);
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_simt_kernel(GemmParams p) {
@@ -210,5 +167,13 @@ static int simt_launch(const GemmParams& pin, hipStream_t st) {
   return MMSA_OK;
 }
 
-int gemm_f32_launch(const GemmParams& p, hipStream_t st) { return simt_launch<float>(p, st); }
+int gemm_f32_valu_launch(const GemmParams& p, hipStream_t st) { return simt_launch<float>(p, st); }
+int gemm_f32_launch(const GemmParams& pin, hipStream_t st) {
+  if (!gemm_f32_mfma_eligible(pin)) return simt_launch<float>(pin, st);
+  GemmParams p = pin;
+  const int slot = gemm_prof_open(p, st);
+  const int rc = gemm_f32_mfma_launch(p, st);
+  gemm_prof_close(slot, st);
+  return rc;
+}
 int gemm_bf16_simt_launch(const GemmParams& p, hipStream_t st) { return simt_launch<bf16>(p, st); }

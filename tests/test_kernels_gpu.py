@@ -11,9 +11,10 @@ pytestmark = pytest.mark.gpu
 
 from multimodal_sentiment_aanalysis_amd import kernels as K
 from multimodal_sentiment_aanalysis_amd._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH, GEMM_BF16_MFMA,
-                                                     GEMM_BF16_SIMT, GEMM_F32_SIMT)
+                                                     GEMM_BF16_SIMT, GEMM_F32_MFMA, GEMM_F32_SIMT, GEMM_F32_VALU)
 
-IMPLS = [(GEMM_F32_SIMT, torch.float32), (GEMM_BF16_MFMA, torch.bfloat16), (GEMM_BF16_SIMT, torch.bfloat16)]
+IMPLS = [(GEMM_F32_SIMT, torch.float32), (GEMM_BF16_MFMA, torch.bfloat16), (GEMM_BF16_SIMT, torch.bfloat16),
+         (GEMM_F32_MFMA, torch.float32)]
 
 
 def rnd(shape, dtype, dev, seed, scale=1.0):
@@ -111,6 +112,45 @@ def test_gemm_f32_n3(dev):
     C = torch.empty(M, N, dtype=torch.float32, device=dev)
     K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, bias=bias, impl=GEMM_F32_SIMT)
     assert_close(C, A.cpu().double() @ B.cpu().double().T + bias.cpu().double(), torch.float32, "N=3")
+
+
+@pytest.mark.parametrize("case", ["nt", "nn", "tn_split", "tn_kc", "edge", "epilogue"])
+def test_gemm_f32_mfma_matches_valu_bitwise(dev, case):
+    """The exact-fp32 matrix-core kernel (v_mfma_f32_32x32x2_f32, gemm_f32_mfma.hip) against the VALU-fma kernel: the MFMA
+    is a k-ordered fmaf chain and both kernels use the same K order and split-K partition, so the results must be EQUAL
+    BIT FOR BIT — every fast loader (k-contiguous, m/n-contiguous), the generic edge loaders, slabs + reducer, epilogues."""
+    f32 = torch.float32
+    if case == "nt":
+        M, N, Kd = 1024, 768, 768
+        A, B = rnd((M, Kd), f32, dev, 1), rnd((N, Kd), f32, dev, 2)
+        run = lambda C, impl: K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, impl=impl)  # noqa: E731
+    elif case == "nn":
+        M, N, Kd = 512, 768, 3072
+        A, B = rnd((M, Kd), f32, dev, 1), rnd((Kd, N), f32, dev, 2)
+        run = lambda C, impl: K.gemm(A, B, C, M, N, Kd, Kd, N, N, b_kmajor=1, impl=impl)  # noqa: E731
+    elif case == "tn_split":
+        M, N, Kd = 768, 768, 4096
+        A, B = rnd((Kd, M), f32, dev, 1), rnd((Kd, N), f32, dev, 2)
+        run = lambda C, impl: K.gemm(A, B, C, M, N, Kd, M, N, N, a_kmajor=1, b_kmajor=1, out_f32=1, split_k=4, impl=impl)  # noqa: E731
+    elif case == "tn_kc":
+        M, N, Kd = 128, 256, 192
+        A, B = rnd((Kd, M), f32, dev, 1), rnd((N, Kd), f32, dev, 2)
+        run = lambda C, impl: K.gemm(A, B, C, M, N, Kd, M, Kd, N, a_kmajor=1, b_kmajor=0, impl=impl)  # noqa: E731
+    elif case == "edge":  # nothing aligned: generic loaders, scalar epilogue
+        M, N, Kd = 77, 261, 203
+        A, B = rnd((M, Kd), f32, dev, 1), rnd((N, Kd), f32, dev, 2)
+        run = lambda C, impl: K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, impl=impl)  # noqa: E731
+    else:
+        M, N, Kd = 200, 192, 128
+        A, B = rnd((M, Kd), f32, dev, 1, 0.3), rnd((N, Kd), f32, dev, 2, 0.3)
+        bias, add = rnd((N,), f32, dev, 3), rnd((M, N), f32, dev, 4)
+        run = lambda C, impl: K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, bias=bias, act=ACT_GELU, add=add, ldadd=N, impl=impl)  # noqa: E731
+    C1 = torch.zeros(M, N, dtype=f32, device=dev)
+    C2 = torch.zeros(M, N, dtype=f32, device=dev)
+    run(C1, GEMM_F32_MFMA)
+    run(C2, GEMM_F32_VALU)
+    assert torch.isfinite(C1).all() and C1.abs().max() > 0
+    assert torch.equal(C1, C2), f"{case}: max |diff| {(C1 - C2).abs().max().item():.3e}"
 
 
 CONVS = [  # B, H, W, Cin, Cout, k, stride, pad
