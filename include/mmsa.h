@@ -169,6 +169,17 @@ int mmsa_resnet_fwd(const mmsa_resnet_cfg* c, const float* w32, const void* wt, 
                     float* feat /*[batch][out_dim] fp32*/, void* stream);
 int mmsa_resnet_bwd(const mmsa_resnet_cfg* c, const float* w32, const void* wt, void* ws, const float* dfeat, float* grad,
                     int32_t accumulate, void* stream);
+/* Backward with a "gradient range ready" callback, for the data-parallel trainer (all-reduce overlapped
+ * with the backward): cb(user, offset, length) is called on the host, from inside the call, each time the kernels producing
+ * grad[offset, offset + length) have been enqueued on `stream` (ranges arrive from the end of the flat buffer to its start
+ * and tile it exactly). BERT: pooler + projection, then layers_per_chunk encoder layers at a time, then the embeddings.
+ * ResNet: projection, stage 4, 3, 2, stage 1 + stem. cb == NULL: identical to the plain entry points. */
+typedef void (*mmsa_range_cb)(void* user, int64_t offset, int64_t length);
+int mmsa_bert_bwd_cb(const mmsa_bert_cfg* c, const float* w32, const void* wt, const int64_t* ids, const float* mask, void* ws,
+                     const float* dfeat, float* grad, int32_t accumulate, void* stream, mmsa_range_cb cb, void* user,
+                     int32_t layers_per_chunk);
+int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* c, const float* w32, const void* wt, void* ws, const float* dfeat, float* grad,
+                       int32_t accumulate, void* stream, mmsa_range_cb cb, void* user);
 
 /* ---- fusion-head engines (fp32) ---------------------------------------------------------------------------------
  * kind 0 CrossModalTransformer (MultimodalModel.py:108-149): inputs {query[B,E], key[B,Lk,E], value[B,Lk,E]} -> {out[B,E]}

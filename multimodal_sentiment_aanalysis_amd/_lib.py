@@ -69,6 +69,8 @@ class HeadCfg(ctypes.Structure):
 
 HEAD_CROSS_MODAL, HEAD_MM_FUSION, HEAD_WEIGHTED, HEAD_CLASSIFIER, HEAD_PROJECTION = 0, 1, 2, 3, 4
 
+RANGE_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64)  # mmsa_range_cb (include/mmsa.h)
+
 _lib = None
 
 
@@ -112,6 +114,8 @@ def _declare(L):
         "mmsa_bert_ws_bytes": (sz, [P(BertCfg)]),
         "mmsa_bert_fwd": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp]),
         "mmsa_bert_bwd": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+        "mmsa_bert_bwd_cb": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp, i32, vp, RANGE_CB, vp, i32]),
+        "mmsa_resnet_bwd_cb": (ctypes.c_int, [P(ResnetCfg), vp, vp, vp, vp, vp, i32, vp, RANGE_CB, vp]),
         "mmsa_resnet_param_count": (ctypes.c_int, [P(ResnetCfg), i32]),
         "mmsa_resnet_param_total": (i64, [P(ResnetCfg), i32]),
         "mmsa_resnet_param_info": (ctypes.c_int, [P(ResnetCfg), i32, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, i64p, i32p, i64p]),

@@ -204,7 +204,19 @@ int mmsa_bert_fwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
 
 int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, const int64_t* ids, const float* mask,
                   void* ws_base, const float* dfeat, float* grad, int32_t accumulate, void* stream) {
+  return mmsa_bert_bwd_cb(cp, w32, wt, ids, mask, ws_base, dfeat, grad, accumulate, stream, nullptr, nullptr, 0);
+}
+
+// The backward with a "gradient range ready" callback: cb(user, offset, length) is called — on the host, from inside this
+// call — each time the kernels that produce the parameter gradients grad[offset, offset + length) have been ENQUEUED on
+// `stream` (pooler + projection first, then `layers_per_chunk` encoder layers at a time from the last layer down, the
+// embeddings last). The data-parallel trainer records an event there and all-reduces that range on a side stream while
+// the remaining backward runs (fused.py GradReducer; Trainer.py:79-81 needs the REDUCED gradients only at the clip).
+int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, const int64_t* ids, const float* mask,
+                     void* ws_base, const float* dfeat, float* grad, int32_t accumulate, void* stream, mmsa_range_cb cb,
+                     void* user, int32_t layers_per_chunk) {
   if (!cp || !bert_cfg_ok(*cp) || !w32 || !wt || !ids || !ws_base || !dfeat || !grad) return MMSA_ERR_ARG;
+  if (layers_per_chunk < 1) layers_per_chunk = 1;
   const mmsa_bert_cfg& c = *cp;
   const BertLayout lay = bert_layout(c);
   BertWs ws = bert_ws(c, ws_base);
@@ -235,6 +247,8 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
   void *dOut = ws.bufA, *bB = ws.bufB, *bC = ws.bufC;
   if (hipMemsetAsync(dOut, 0, (size_t)M * H * es, st) != hipSuccess) return MMSA_ERR_LAUNCH;
   RET_IF(e.linear_dgrad(ws.dprepool, H, W(lay.wp), dOut, (long)S * H, B, H, H));  // only the [CLS] rows receive gradient
+  if (cb) cb(user, lay.wp, lay.t.total - lay.wp);
+  long chunk_end = lay.wp;  // encoder layers [l, ...) up to chunk_end are complete but not yet announced
 
   for (int l = c.layers - 1; l >= 0; --l) {
     const BertLayerOff& f = lay.L[l];
@@ -270,6 +284,10 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
     }
     // rotate: dx becomes the next layer's dOut
     void* t = dOut; dOut = bC; bC = t;
+    if (cb && ((c.layers - l) % layers_per_chunk == 0 || l == 0)) {
+      cb(user, f.wqkv, chunk_end - f.wqkv);
+      chunk_end = f.wqkv;
+    }
   }
   // embeddings
   void* de = bB;
@@ -279,6 +297,7 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
     return MMSA_ERR_LAUNCH;
   RET_IF(embed_backward(c.dtype, (const long long*)ids, de, G(lay.word), G(lay.pos), G(lay.type), acc, ws.colws, B, S, H,
                         c.vocab, c.max_pos, st));
+  if (cb) cb(user, 0, lay.L[0].wqkv);
   return MMSA_OK;
 }
 

@@ -392,6 +392,14 @@ int mmsa_resnet_fwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
 
 int mmsa_resnet_bwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt, void* ws_base, const float* dfeat, float* grad,
                     int32_t accumulate, void* stream) {
+  return mmsa_resnet_bwd_cb(cp, w32, wt, ws_base, dfeat, grad, accumulate, stream, nullptr, nullptr);
+}
+
+// The backward with a "gradient range ready" callback (see mmsa_bert_bwd_cb): the projection first, then one range per
+// stage from stage 4 down (announced when the stage's first bottleneck — the last one the backward reaches — is done),
+// the stem last.
+int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* wt, void* ws_base, const float* dfeat,
+                       float* grad, int32_t accumulate, void* stream, mmsa_range_cb cb, void* user) {
   if (!cp || !res_cfg_ok(*cp) || !w32 || !wt || !ws_base || !dfeat || !grad) return MMSA_ERR_ARG;
   const mmsa_resnet_cfg& c = *cp;
   const ResLayout L = res_layout(c);
@@ -407,6 +415,8 @@ int mmsa_resnet_bwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
   RET_IF(r.e.linear_dgrad(ws.dfeat_t, D, r.W(L.wproj), ws.dpooled, L.feat_c, B, D, L.feat_c));
   void *dOut = ws.g0, *t1 = ws.g1, *t2 = ws.g2, *t3 = ws.g3;
   RET_IF(avgpool_bwd(c.dtype, ws.dpooled, dOut, B, L.Hf * L.Wf, L.feat_c, st));
+  if (cb) cb(user, L.wproj, L.t.total - L.wproj);
+  long chunk_end = L.wproj;
   for (int i = (int)L.blocks.size() - 1; i >= 0; --i) {
     const BlockDef& bd = L.blocks[i];
     BlockWs& bw = ws.blocks[i];
@@ -434,6 +444,10 @@ int mmsa_resnet_bwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
     } else {
       RET_IF(conv_dgrad(r, bd.c1, t1, dOut, skip));     // dx -> dOut (its old content was consumed by bn3's backward)
     }
+    if (cb && bd.has_ds) {  // first bottleneck of a stage: the whole stage's gradients are enqueued
+      cb(user, bd.c1.w, chunk_end - bd.c1.w);
+      chunk_end = bd.c1.w;
+    }
   }
   // max-pool, stem BN + ReLU, stem conv (weight gradient only: the image needs none)
   const ConvDef& s = L.stem;
@@ -449,6 +463,7 @@ int mmsa_resnet_bwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
     RET_IF(r.e.gemm(p));
   }
   RET_IF(unpad_rows(ws.stem_dw, r.G(s.w), 64, L.Kstem_pad, 147, acc, st));
+  if (cb) cb(user, 0, chunk_end);
   return MMSA_OK;
 }
 

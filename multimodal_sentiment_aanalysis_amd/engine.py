@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (HEAD_CLASSIFIER, HEAD_CROSS_MODAL, HEAD_MM_FUSION, HEAD_PROJECTION, HEAD_WEIGHTED, MMSA_BF16,
-                   MMSA_F32, BertCfg, HeadCfg, MmsaError, ResnetCfg, check, param_table, ptr, ptr_array,
+                   MMSA_F32, RANGE_CB, BertCfg, HeadCfg, MmsaError, ResnetCfg, check, param_table, ptr, ptr_array,
                    stream_ptr)
 
 BERT_BASE = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, max_pos=512, type_vocab=2,
@@ -175,6 +175,25 @@ class EngineModule(nn.Module):
     def _any_trainable(self):
         return any(p.requires_grad for p in self._pmap.values())
 
+    # ---- gradient-range hook (data parallel) ------------------------------------------------------------------------
+    # `_grad_range_hook(eng, offset, length)` (set by FusedTrainStep when world > 1) is called from INSIDE the encoder's
+    # backward C call each time the kernels producing grad[offset, offset + length) (engine-relative elements) have been
+    # enqueued: a few encoder layers / one ResNet stage at a time, so the all-reduce of that range starts while the rest of
+    # the backward is still running. `_grad_ready_hook(eng)` still fires once at the end of the engine's backward.
+    def _range_cb(self):
+        hook = getattr(self, "_grad_range_hook", None)
+        if hook is None:
+            return RANGE_CB()  # NULL function pointer: the plain backward
+        cb = getattr(self, "_range_cb_obj", None)
+        if cb is None or getattr(self, "_range_cb_for", None) is not hook:
+            def trampoline(_user, off, length, _self=self):
+                h = getattr(_self, "_grad_range_hook", None)
+                if h is not None:
+                    h(_self, int(off), int(length))
+            cb = RANGE_CB(trampoline)
+            self._range_cb_obj, self._range_cb_for = cb, hook  # keep the ctypes thunk alive
+        return cb
+
     # ---- working copy in the storage dtype ------------------------------------------------------------------------
     def _storage_code(self):
         return MMSA_BF16 if self.precision == "bf16" else MMSA_F32
@@ -324,9 +343,10 @@ class _BertFn(torch.autograd.Function):
     def backward(ctx, dfeat):
         eng = ctx.eng
         eng._ensure_grads()
-        check(_lib.load().mmsa_bert_bwd(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ids), ptr(ctx.mask),
-                                        ptr(ctx.ws), ptr(dfeat.contiguous()), ptr(eng._flat_g), eng._acc_flag(),
-                                        stream_ptr()), "mmsa_bert_bwd")
+        check(_lib.load().mmsa_bert_bwd_cb(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ids),
+                                           ptr(ctx.mask), ptr(ctx.ws), ptr(dfeat.contiguous()), ptr(eng._flat_g),
+                                           eng._acc_flag(), stream_ptr(), eng._range_cb(), None,
+                                           int(getattr(eng, "layers_per_chunk", 3))), "mmsa_bert_bwd")
         eng._give_ws(ctx.ws)
         ctx.ws = None
         if getattr(eng, "_grad_ready_hook", None) is not None:
@@ -415,9 +435,9 @@ class _ResnetFn(torch.autograd.Function):
         dfeat = dfeat.contiguous()
         side = eng._run_stream()
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            check(_lib.load().mmsa_resnet_bwd(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ws),
-                                              ptr(dfeat), ptr(eng._flat_g), eng._acc_flag(), stream_ptr()),
-                  "mmsa_resnet_bwd")
+            check(_lib.load().mmsa_resnet_bwd_cb(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ws),
+                                                 ptr(dfeat), ptr(eng._flat_g), eng._acc_flag(), stream_ptr(),
+                                                 eng._range_cb(), None), "mmsa_resnet_bwd")
             if side is not None:
                 dfeat.record_stream(side)
             eng._give_ws(ctx.ws)

@@ -9,6 +9,7 @@
     (mmsa_grad_norm, mmsa_adamw_step), the 1/world_size average folded into their grad_scale.
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -19,15 +20,23 @@ from .engine import HeadEngine, engines_of, materialize
 
 
 class GradReducer:
-    """Bucketed SUM all-reduce of contiguous gradient ranges. On GPU the collectives run on a side stream ordered
-    after an event recorded when the range's producer kernels were enqueued; `finish()` makes the current stream wait.
-    Works on CPU tensors with the gloo backend too (used by the world_size-2 CPU tests)."""
+    """Bucketed SUM all-reduce of gradient ranges, overlapped with the backward that produces them.
 
-    def __init__(self, flat_g, bucket_bytes=64 << 20, group=None):
+    The encoder backwards announce their gradient ranges a few layers / one stage at a time (mmsa_*_bwd_cb: ranges arrive from
+    the end of an engine's parameters to their start). `add()` coalesces adjacent announcements until `min_bucket_bytes` are
+    pending, then records an event on the producing stream and issues the all-reduce (split at `bucket_bytes`) on a SIDE
+    stream that waits for that event only — so the collective of the last layers runs under the backward of the earlier
+    ones. `finish()` joins the side stream before the clip. Works on CPU tensors with the gloo backend too (used by the
+    world_size-2 CPU tests), where the collectives run inline."""
+
+    def __init__(self, flat_g, bucket_bytes=64 << 20, group=None, min_bucket_bytes=16 << 20):
         self.flat_g, self.group = flat_g, group
         self.bucket_elems = max(1, bucket_bytes // flat_g.element_size())
+        self.min_elems = max(1, min_bucket_bytes // flat_g.element_size())
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.works = []
+        self.pending = None  # (start, length) announced, not yet issued
+        self.issued = []     # (start, length) of every collective of the current step, in issue order (tests, DESIGN §6)
         self.stream = torch.cuda.Stream(device=flat_g.device) if flat_g.is_cuda else None
 
     def buckets(self, start, length):
@@ -37,6 +46,32 @@ class GradReducer:
             out.append((a, b))
             a = b
         return out
+
+    def add(self, start, length):
+        """Announce grad[start, start + length) as enqueued. Adjacent ranges (either side) are merged; a non-adjacent one
+        flushes what was pending."""
+        if self.world == 1 or length <= 0:
+            return
+        if self.pending is not None:
+            ps, pl = self.pending
+            if start + length == ps:
+                self.pending = (start, pl + length)
+            elif ps + pl == start:
+                self.pending = (ps, pl + length)
+            else:
+                self.flush()
+                self.pending = (start, length)
+        else:
+            self.pending = (start, length)
+        if self.pending[1] >= self.min_elems:
+            self.flush()
+
+    def flush(self):
+        if self.pending is None:
+            return
+        start, length = self.pending
+        self.pending = None
+        self.reduce_range(start, length)
 
     def reduce_range(self, start, length):
         if self.world == 1 or length <= 0:
@@ -49,12 +84,18 @@ class GradReducer:
                 for a, b in self.buckets(start, length):
                     self.works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group,
                                                       async_op=True))
+                    self.issued.append((a, b - a))
         else:
             for a, b in self.buckets(start, length):
                 self.works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group,
                                                   async_op=True))
+                self.issued.append((a, b - a))
+
+    def begin_step(self):
+        self.issued = []
 
     def finish(self):
+        self.flush()
         for w in self.works:
             w.wait()
         self.works = []
@@ -128,6 +169,11 @@ class FusedTrainStep:
         self.opt = FlatAdamW(self.state, lr, weight_decay, betas, eps, max_norm)
         self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.world > 1:
+            # A workgroup of the persistent GEMM fills its CU (registers + LDS): a collective's blocks cannot co-reside with
+            # it and would wait for whole CUs, while the GEMM behind them ran a second round of tiles. Leave the collective
+            # 16 of the 256 CUs (2 per XCD) for the whole run; read once by the library at its first GEMM launch.
+            os.environ.setdefault("MMSA_G2_CUS", "240")
         self.reducer = GradReducer(self.state.flat_g, bucket_bytes) if self.world > 1 else None
         if self.world > 1:  # identical replicas: parameters and BN buffers from rank 0
             dist.broadcast(self.state.flat_w, 0)
@@ -140,11 +186,20 @@ class FusedTrainStep:
             self._image_net.use_side_stream(True)
         self._ranges = {id(e): (off, n) for e, off, n in self.state.ranges}
         for e, off, n in self.state.ranges:
-            e._grad_ready_hook = self._on_grads_ready if self.reducer is not None else None
+            on = self.reducer is not None
+            e._grad_ready_hook = self._on_grads_ready if on else None
+            e._grad_range_hook = self._on_range_ready if on and not isinstance(e, HeadEngine) else None
 
-    def _on_grads_ready(self, eng):
-        off, n = self._ranges[id(eng)]
-        self.reducer.reduce_range(off, n)
+    def _on_range_ready(self, eng, off, length):  # from inside the encoder's backward: a few layers / a stage at a time
+        base, _n = self._ranges[id(eng)]
+        self.reducer.add(base + off, length)
+
+    def _on_grads_ready(self, eng):  # end of an engine's backward
+        if isinstance(eng, HeadEngine):
+            off, n = self._ranges[id(eng)]
+            self.reducer.add(off, n)
+        else:
+            self.reducer.flush()  # the encoder announced everything itself; push out what is still pending
 
     def step(self, image, token_ids, attention_mask, labels):
         if not self.state.valid():
@@ -152,6 +207,8 @@ class FusedTrainStep:
         L = _lib.load()
         model = self.model
         model.train()
+        if self.reducer is not None:
+            self.reducer.begin_step()
         for e, _, _ in self.state.ranges:
             e._overwrite_next = True  # every gradient range is written (not accumulated) by this backward
         logits, _aux = model(image, token_ids, attention_mask, labels)

