@@ -240,7 +240,7 @@ def attn_ref(qkv, mask, dctx, B, S, heads):
     return ctx.detach(), t.grad.reshape(B * S, 3 * Hd)
 
 
-@pytest.mark.parametrize("impl,dtype", IMPLS)
+@pytest.mark.parametrize("impl,dtype", IMPLS[:3])  # attention: fp32 SIMT, bf16 MFMA, bf16 SIMT (no GEMM-only impls)
 @pytest.mark.parametrize("B,S,heads,masked", [(2, 128, 2, False), (3, 32, 4, True), (2, 64, 1, True), (1, 16, 2, False),
                                               (2, 48, 2, True), (1, 256, 1, False)])
 def test_attention(dev, impl, dtype, B, S, heads, masked):
