@@ -177,9 +177,14 @@ int mmsa_resnet_bwd(const mmsa_resnet_cfg* c, const float* w32, const void* wt, 
 typedef void (*mmsa_range_cb)(void* user, int64_t offset, int64_t length);
 int mmsa_bert_bwd_cb(const mmsa_bert_cfg* c, const float* w32, const void* wt, const int64_t* ids, const float* mask, void* ws,
                      const float* dfeat, float* grad, int32_t accumulate, void* stream, mmsa_range_cb cb, void* user,
-                     int32_t layers_per_chunk);
+                     int32_t layers_per_chunk, const uint8_t* frozen);
 int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* c, const float* w32, const void* wt, void* ws, const float* dfeat, float* grad,
-                       int32_t accumulate, void* stream, mmsa_range_cb cb, void* user);
+                       int32_t accumulate, void* stream, mmsa_range_cb cb, void* user, const uint8_t* frozen);
+/* `frozen` (host array, one byte per entry of the engine's parameter table, NULL = everything trainable): SURVEY.md §8f N2 — the
+ * reference's curriculum phases (dataLoader/MultiTaskTrainer.py:50-177) and fine-tuning (train.py:90-92) freeze sub-graphs. A
+ * wholly frozen group (BERT: embeddings / one encoder layer / pooler + projection; ResNet: stem / one bottleneck / projection)
+ * gets no weight-gradient kernels, the backward stops below the lowest trainable group, and only ranges holding trainable
+ * parameters are announced through cb. Gradients of frozen entries are left undefined (not read by anything). */
 
 /* ---- fusion-head engines (fp32) ---------------------------------------------------------------------------------
  * kind 0 CrossModalTransformer (MultimodalModel.py:108-149): inputs {query[B,E], key[B,Lk,E], value[B,Lk,E]} -> {out[B,E]}
@@ -252,6 +257,9 @@ int mmsa_grad_norm_guard(const float* g, int64_t n, float grad_scale, float max_
  * the trainable sub-ranges of a curriculum phase (dataLoader/MultiTaskTrainer.py:50-177 freezes everything else) */
 int mmsa_grad_norm_ranges(const float* g, const int64_t* offsets, const int64_t* lengths, int32_t nranges, float grad_scale,
                           float max_norm, const float* loss, int32_t* step_count, float* norm_out, void* ws, void* stream);
+/* g[0, n) *= norm_clip[1] (no-op on a skipped step): the in-place scaling clip_grad_norm_ applies to gradients that no
+ * optimizer owns (phase 3 of dataLoader/MultiTaskTrainer.py:147-177 clips four modules and steps one) */
+int mmsa_grad_scale_clip(float* g, int64_t n, const float* norm_clip, void* stream);
 int mmsa_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w16, int64_t n, float lr, float beta1, float beta2,
                         float eps, float weight_decay, const int32_t* step_count, const float* norm_clip, float grad_scale,
                         void* stream);

@@ -114,8 +114,8 @@ def _declare(L):
         "mmsa_bert_ws_bytes": (sz, [P(BertCfg)]),
         "mmsa_bert_fwd": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp]),
         "mmsa_bert_bwd": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp, i32, vp]),
-        "mmsa_bert_bwd_cb": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp, i32, vp, RANGE_CB, vp, i32]),
-        "mmsa_resnet_bwd_cb": (ctypes.c_int, [P(ResnetCfg), vp, vp, vp, vp, vp, i32, vp, RANGE_CB, vp]),
+        "mmsa_bert_bwd_cb": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp, i32, vp, RANGE_CB, vp, i32, vp]),
+        "mmsa_resnet_bwd_cb": (ctypes.c_int, [P(ResnetCfg), vp, vp, vp, vp, vp, i32, vp, RANGE_CB, vp, vp]),
         "mmsa_resnet_param_count": (ctypes.c_int, [P(ResnetCfg), i32]),
         "mmsa_resnet_param_total": (i64, [P(ResnetCfg), i32]),
         "mmsa_resnet_param_info": (ctypes.c_int, [P(ResnetCfg), i32, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, i64p, i32p, i64p]),
@@ -138,6 +138,7 @@ def _declare(L):
         "mmsa_adamw_step": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp]),
         "mmsa_grad_norm_guard": (ctypes.c_int, [vp, i64, f32, f32, vp, vp, vp, vp, vp]),
         "mmsa_grad_norm_ranges": (ctypes.c_int, [vp, i64p, i64p, i32, f32, f32, vp, vp, vp, vp, vp]),
+        "mmsa_grad_scale_clip": (ctypes.c_int, [vp, i64, vp, vp]),
         "mmsa_adamw_step_dev": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, f32, vp]),
         "mmsa_cast_f32": (ctypes.c_int, [i32, vp, vp, i64, vp]),
         "mmsa_prof_begin": (ctypes.c_int, [i32]),

@@ -204,7 +204,7 @@ int mmsa_bert_fwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
 
 int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, const int64_t* ids, const float* mask,
                   void* ws_base, const float* dfeat, float* grad, int32_t accumulate, void* stream) {
-  return mmsa_bert_bwd_cb(cp, w32, wt, ids, mask, ws_base, dfeat, grad, accumulate, stream, nullptr, nullptr, 0);
+  return mmsa_bert_bwd_cb(cp, w32, wt, ids, mask, ws_base, dfeat, grad, accumulate, stream, nullptr, nullptr, 0, nullptr);
 }
 
 // The backward with a "gradient range ready" callback: cb(user, offset, length) is called — on the host, from inside this
@@ -214,7 +214,7 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
 // the remaining backward runs (fused.py GradReducer; Trainer.py:79-81 needs the REDUCED gradients only at the clip).
 int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, const int64_t* ids, const float* mask,
                      void* ws_base, const float* dfeat, float* grad, int32_t accumulate, void* stream, mmsa_range_cb cb,
-                     void* user, int32_t layers_per_chunk) {
+                     void* user, int32_t layers_per_chunk, const uint8_t* frozen) {
   if (!cp || !bert_cfg_ok(*cp) || !w32 || !wt || !ids || !ws_base || !dfeat || !grad) return MMSA_ERR_ARG;
   if (layers_per_chunk < 1) layers_per_chunk = 1;
   const mmsa_bert_cfg& c = *cp;
@@ -224,6 +224,24 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
   Eng e{c.dtype, st, ws.splitk, ws.splitk_bytes, ws.colws};
   const size_t es = e.esz();
   const int M = c.batch * c.seq, H = c.hidden, I = c.intermediate, S = c.seq, B = c.batch, D = c.out_dim;
+  // Frozen parameter groups (N2: the curriculum phases of dataLoader/MultiTaskTrainer.py:50-177 and train.py:90-92 freeze
+  // sub-graphs; `frozen[i]` = 1 for entry i of the parameter table): a wholly frozen encoder layer skips its four weight-
+  // gradient GEMMs (half of its backward FLOPs), and the backward stops below the lowest trainable group (no data gradient is
+  // computed for anything that nothing trainable is reached through). Entries: 5 embedding tensors, 16 per layer, 4 tail.
+  const int nl = c.layers;
+  auto all_frozen = [&](int first, int count) {
+    if (!frozen) return false;
+    for (int i = first; i < first + count; ++i)
+      if (!frozen[i]) return false;
+    return true;
+  };
+  const bool emb_frozen = all_frozen(0, 5), tail_frozen = all_frozen(5 + 16 * nl, 4);
+  std::vector<char> layer_frozen(nl);
+  int lowest = emb_frozen ? nl : -1;  // lowest trainable group: -1 = embeddings, l = encoder layer l, nl = none below the tail
+  for (int l = nl - 1; l >= 0; --l) {
+    layer_frozen[l] = all_frozen(5 + 16 * l, 16);
+    if (!layer_frozen[l] && emb_frozen) lowest = l;
+  }
   if (c.dtype == MMSA_BF16) {  // bias gradients ride in the grouped weight-gradient launch (Eng::wgrad_group)
     RET_IF(fill_ones_bf16(ws.ones8, (long)M * 8, st));
     e.ones8 = ws.ones8;
@@ -238,22 +256,30 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
   const void* xL = ws.L[c.layers - 1].out;
   // projection + pooler
   RET_IF(cast_f32(c.dtype, dfeat, ws.dfeat_t, (long)B * D, st));
-  RET_IF(e.bias_grad(ws.dfeat_t, D, G(lay.bproj), B, D, acc));
-  RET_IF(e.linear_wgrad(ws.dfeat_t, D, ws.pooled, H, G(lay.wproj), B, D, H, acc));
+  if (!tail_frozen) {
+    RET_IF(e.bias_grad(ws.dfeat_t, D, G(lay.bproj), B, D, acc));
+    RET_IF(e.linear_wgrad(ws.dfeat_t, D, ws.pooled, H, G(lay.wproj), B, D, H, acc));
+  }
+  if (tail_frozen && lowest == nl) return MMSA_OK;  // nothing trainable in this encoder
   RET_IF(e.linear_dgrad(ws.dfeat_t, D, W(lay.wproj), ws.dpool, H, B, D, H));
   RET_IF(tanh_bwd(c.dtype, ws.dpool, ws.pooled, ws.dprepool, (long)B * H, st));
-  RET_IF(e.bias_grad(ws.dprepool, H, G(lay.bp), B, H, acc));
-  RET_IF(e.linear_wgrad(ws.dprepool, H, xL, (long)S * H, G(lay.wp), B, H, H, acc));
+  if (!tail_frozen) {
+    RET_IF(e.bias_grad(ws.dprepool, H, G(lay.bp), B, H, acc));
+    RET_IF(e.linear_wgrad(ws.dprepool, H, xL, (long)S * H, G(lay.wp), B, H, H, acc));
+    if (cb) cb(user, lay.wp, lay.t.total - lay.wp);
+  }
+  if (lowest == nl) return MMSA_OK;  // every encoder layer and the embeddings are frozen: the backward ends here
   void *dOut = ws.bufA, *bB = ws.bufB, *bC = ws.bufC;
   if (hipMemsetAsync(dOut, 0, (size_t)M * H * es, st) != hipSuccess) return MMSA_ERR_LAUNCH;
   RET_IF(e.linear_dgrad(ws.dprepool, H, W(lay.wp), dOut, (long)S * H, B, H, H));  // only the [CLS] rows receive gradient
-  if (cb) cb(user, lay.wp, lay.t.total - lay.wp);
   long chunk_end = lay.wp;  // encoder layers [l, ...) up to chunk_end are complete but not yet announced
+  bool chunk_live = false;  // does the pending chunk hold a trainable layer?
 
-  for (int l = c.layers - 1; l >= 0; --l) {
+  for (int l = c.layers - 1; l >= 0 && l >= lowest; --l) {
     const BertLayerOff& f = lay.L[l];
     BertLayerWs& a = ws.L[l];
     const void* xin = l == 0 ? ws.x0 : ws.L[l - 1].out;
+    const bool last_needed = (l == lowest);  // nothing trainable below: this layer's input needs no gradient
     void* ds2 = bB;
     // ds2 is also dY of the FFN output Linear: its bias gradient (column sums of ds2) comes out of the same pass
     RET_IF(layernorm_bwd(c.dtype, dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, G(f.ln2w), G(f.ln2b), acc, ws.lnws, M, H, st,
@@ -270,10 +296,12 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
     void* dqkv = ws.bufQ;
     RET_IF(attention_bwd(aimpl, a.qkv, mask, dctx, dqkv, ws.attnws, B, S, c.heads, 64, st));
     void* dx = bC;
-    RET_IF(e.linear_dgrad(dqkv, 3 * H, W(f.wqkv), dx, H, M, 3 * H, H, nullptr, 0, ds1, H));  // + residual branch
+    if (!last_needed)
+      RET_IF(e.linear_dgrad(dqkv, 3 * H, W(f.wqkv), dx, H, M, 3 * H, H, nullptr, 0, ds1, H));  // + residual branch
     // the layer's four weight gradients (K = B*S rows each, 18-72 tiles of 256x128) as one launch: together they fill
     // the chip without a K split; the two bias gradients the LayerNorm backward does not produce ride along as column sums
-    {
+    if (!layer_frozen[l]) {
+      chunk_live = true;
       const Eng::WgradJob jobs[4] = {
           {ds2, H, a.act, I, G(f.w2), nullptr, H, I},
           {dpre, I, a.h1, H, G(f.w1), G(f.b1), I, H},
@@ -284,11 +312,13 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
     }
     // rotate: dx becomes the next layer's dOut
     void* t = dOut; dOut = bC; bC = t;
-    if (cb && ((c.layers - l) % layers_per_chunk == 0 || l == 0)) {
-      cb(user, f.wqkv, chunk_end - f.wqkv);
+    if ((c.layers - l) % layers_per_chunk == 0 || l == 0 || last_needed) {
+      if (cb && chunk_live) cb(user, f.wqkv, chunk_end - f.wqkv);
       chunk_end = f.wqkv;
+      chunk_live = false;
     }
   }
+  if (lowest >= 0) return MMSA_OK;  // the embeddings are frozen
   // embeddings
   void* de = bB;
   RET_IF(layernorm_bwd(c.dtype, dOut, ws.e, ws.mean0, ws.rstd0, P(lay.lnw), de, G(lay.lnw), G(lay.lnb), acc, ws.lnws, M, H, st));

@@ -120,6 +120,10 @@ int mmsa_grad_norm_ranges(const float* g, const int64_t* offsets, const int64_t*
   return grad_norm_ranges(g, (const long*)offsets, (const long*)lengths, nranges, grad_scale, max_norm, norm_out, ws,
                           (hipStream_t)stream, loss, step_count);
 }
+int mmsa_grad_scale_clip(float* g, int64_t n, const float* norm_clip, void* stream) {
+  if (!g || !norm_clip) return MMSA_ERR_ARG;
+  return grad_scale_clip(g, n, norm_clip, (hipStream_t)stream);
+}
 int mmsa_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w16, int64_t n, float lr, float beta1, float beta2,
                         float eps, float weight_decay, const int32_t* step_count, const float* norm_clip, float grad_scale,
                         void* stream) {

@@ -86,6 +86,22 @@ int grad_norm(const float* g, long n, float grad_scale, float max_norm, float* n
   return MMSA_OK;
 }
 
+// g *= clip coefficient (norm_clip[1]; nothing when the step is skipped): torch's clip_grad_norm_ scales EVERY gradient it was
+// given in place, also those no optimizer owns — the reference's phase 3 (MultiTaskTrainer.py:147-177) clips four modules'
+// gradients but steps (and zeroes) only the valence head's, so the others keep accumulating the scaled values.
+__global__ __launch_bounds__(256) void grad_scale_clip_kernel(float* __restrict__ g, long n, const float* __restrict__ norm_clip) {
+  const float c = norm_clip[1];
+  if (c < 0.f || c == 1.f) return;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] *= c;
+}
+int grad_scale_clip(float* g, long n, const float* norm_clip, hipStream_t st) {
+  if (n <= 0) return MMSA_ERR_ARG;
+  const int blocks = (int)min((n + 255) / 256, 2048L);
+  hipLaunchKernelGGL(grad_scale_clip_kernel, dim3(blocks), dim3(256), 0, st, g, n, norm_clip);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
 // torch.optim.AdamW (decoupled weight decay on every parameter, bias-corrected):
 //   w *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; w -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,

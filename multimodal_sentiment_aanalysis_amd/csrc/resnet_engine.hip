@@ -392,14 +392,14 @@ int mmsa_resnet_fwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
 
 int mmsa_resnet_bwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt, void* ws_base, const float* dfeat, float* grad,
                     int32_t accumulate, void* stream) {
-  return mmsa_resnet_bwd_cb(cp, w32, wt, ws_base, dfeat, grad, accumulate, stream, nullptr, nullptr);
+  return mmsa_resnet_bwd_cb(cp, w32, wt, ws_base, dfeat, grad, accumulate, stream, nullptr, nullptr, nullptr);
 }
 
 // The backward with a "gradient range ready" callback (see mmsa_bert_bwd_cb): the projection first, then one range per
 // stage from stage 4 down (announced when the stage's first bottleneck — the last one the backward reaches — is done),
 // the stem last.
 int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* wt, void* ws_base, const float* dfeat,
-                       float* grad, int32_t accumulate, void* stream, mmsa_range_cb cb, void* user) {
+                       float* grad, int32_t accumulate, void* stream, mmsa_range_cb cb, void* user, const uint8_t* frozen) {
   if (!cp || !res_cfg_ok(*cp) || !w32 || !wt || !ws_base || !dfeat || !grad) return MMSA_ERR_ARG;
   const mmsa_resnet_cfg& c = *cp;
   const ResLayout L = res_layout(c);
@@ -408,47 +408,81 @@ int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* 
   ResCtx r{c, Eng{c.dtype, st, ws.splitk, ws.splitk_bytes, ws.colws}, w32, wt, nullptr, grad, accumulate ? 1 : 0,
            (size_t)(c.dtype == MMSA_BF16 ? 2 : 4)};
   const int B = c.batch, D = c.out_dim, acc = r.acc;
+  // Frozen parameter groups (see mmsa_bert_bwd_cb): parameter-table entries are 3 for the stem (conv, BN weight, BN bias),
+  // 9 (+3 with a downsample branch) per bottleneck, 2 for the projection. A wholly frozen bottleneck skips its weight-gradient
+  // GEMMs (its BatchNorm backward still runs: the data gradient passes through it); the backward stops below the lowest
+  // trainable group.
+  const int nb = (int)L.blocks.size();
+  std::vector<int> first(nb + 1);
+  {
+    int idx = 3;
+    for (int i = 0; i < nb; ++i) { first[i] = idx; idx += L.blocks[i].has_ds ? 12 : 9; }
+    first[nb] = idx;
+  }
+  auto all_frozen = [&](int lo, int hi) {
+    if (!frozen) return false;
+    for (int i = lo; i < hi; ++i)
+      if (!frozen[i]) return false;
+    return true;
+  };
+  const bool stem_frozen = all_frozen(0, 3), tail_frozen = all_frozen(first[nb], first[nb] + 2);
+  std::vector<char> blk_frozen(nb);
+  int lowest = stem_frozen ? nb : -1;  // -1: stem trainable; i: bottleneck i is the lowest trainable group; nb: none below the tail
+  for (int i = nb - 1; i >= 0; --i) {
+    blk_frozen[i] = all_frozen(first[i], first[i + 1]);
+    if (!blk_frozen[i] && stem_frozen) lowest = i;
+  }
   // projection
   RET_IF(cast_f32(c.dtype, dfeat, ws.dfeat_t, (long)B * D, st));
-  RET_IF(r.e.bias_grad(ws.dfeat_t, D, r.G(L.bproj), B, D, acc));
-  RET_IF(r.e.linear_wgrad(ws.dfeat_t, D, ws.pooled, L.feat_c, r.G(L.wproj), B, D, L.feat_c, acc));
+  if (!tail_frozen) {
+    RET_IF(r.e.bias_grad(ws.dfeat_t, D, r.G(L.bproj), B, D, acc));
+    RET_IF(r.e.linear_wgrad(ws.dfeat_t, D, ws.pooled, L.feat_c, r.G(L.wproj), B, D, L.feat_c, acc));
+    if (cb) cb(user, L.wproj, L.t.total - L.wproj);
+  }
+  if (lowest == nb) return MMSA_OK;  // stem and every bottleneck frozen
   RET_IF(r.e.linear_dgrad(ws.dfeat_t, D, r.W(L.wproj), ws.dpooled, L.feat_c, B, D, L.feat_c));
   void *dOut = ws.g0, *t1 = ws.g1, *t2 = ws.g2, *t3 = ws.g3;
   RET_IF(avgpool_bwd(c.dtype, ws.dpooled, dOut, B, L.Hf * L.Wf, L.feat_c, st));
-  if (cb) cb(user, L.wproj, L.t.total - L.wproj);
   long chunk_end = L.wproj;
-  for (int i = (int)L.blocks.size() - 1; i >= 0; --i) {
+  bool chunk_live = false;
+  for (int i = (int)L.blocks.size() - 1; i >= 0 && i >= lowest; --i) {
     const BlockDef& bd = L.blocks[i];
+    const bool wg = !blk_frozen[i], last_needed = (i == lowest);
+    chunk_live = chunk_live || wg;
     BlockWs& bw = ws.blocks[i];
     const void* xin = i == 0 ? ws.pool : ws.blocks[i - 1].c3.y;
     // out = relu(bn3(z3) + idn): dz3 -> t1, masked gradient of the identity branch -> t2
     RET_IF(bn_bwd(r, bd.c3, bw.c3, dOut, bw.c3.y, t1, t2, MMSA_ACT_RELU, ws.bnws));
-    RET_IF(conv_wgrad(r, bd.c3, t1, bw.c2.y, r.G(bd.c3.w), acc));
+    if (wg) RET_IF(conv_wgrad(r, bd.c3, t1, bw.c2.y, r.G(bd.c3.w), acc));
     RET_IF(conv_dgrad(r, bd.c3, t1, t3, nullptr));                                   // dy2 -> t3
     RET_IF(bn_bwd(r, bd.c2, bw.c2, t3, nullptr, t1, nullptr, MMSA_ACT_RELU, ws.bnws));  // dz2 -> t1
-    RET_IF(conv_wgrad(r, bd.c2, t1, bw.c1.y, r.G(bd.c2.w), acc));
+    if (wg) RET_IF(conv_wgrad(r, bd.c2, t1, bw.c1.y, r.G(bd.c2.w), acc));
     RET_IF(conv_dgrad(r, bd.c2, t1, t3, nullptr));                                   // dy1 -> t3
     RET_IF(bn_bwd(r, bd.c1, bw.c1, t3, nullptr, t1, nullptr, MMSA_ACT_RELU, ws.bnws));  // dz1 -> t1
     if (const char* dbg = getenv("MMSA_RESNET_BWD_STOP_BLOCK")) {  // diagnostic: leave t3 = dy1, t1 = dz1 of block i intact
       if (atoi(dbg) == i) return MMSA_OK;
     }
-    RET_IF(conv_wgrad(r, bd.c1, t1, xin, r.G(bd.c1.w), acc));
+    if (wg) RET_IF(conv_wgrad(r, bd.c1, t1, xin, r.G(bd.c1.w), acc));
     const void* skip = t2;  // identity block: the skip gradient is added to conv1's data gradient
     if (bd.has_ds) {
       RET_IF(bn_bwd(r, bd.ds, bw.ds, t2, nullptr, t3, nullptr, MMSA_ACT_NONE, ws.bnws));  // dzd -> t3
-      RET_IF(conv_wgrad(r, bd.ds, t3, xin, r.G(bd.ds.w), acc));
-      RET_IF(conv_dgrad(r, bd.ds, t3, dOut, nullptr));  // dOut is free: holds the projected-skip data gradient
-      skip = dOut;
-      RET_IF(conv_dgrad(r, bd.c1, t1, t2, skip));       // dx -> t2
-      void* t = dOut; dOut = t2; t2 = t;
-    } else {
+      if (wg) RET_IF(conv_wgrad(r, bd.ds, t3, xin, r.G(bd.ds.w), acc));
+      if (!last_needed) {
+        RET_IF(conv_dgrad(r, bd.ds, t3, dOut, nullptr));  // dOut is free: holds the projected-skip data gradient
+        skip = dOut;
+        RET_IF(conv_dgrad(r, bd.c1, t1, t2, skip));       // dx -> t2
+        void* t = dOut; dOut = t2; t2 = t;
+      }
+    } else if (!last_needed) {
       RET_IF(conv_dgrad(r, bd.c1, t1, dOut, skip));     // dx -> dOut (its old content was consumed by bn3's backward)
     }
-    if (cb && bd.has_ds) {  // first bottleneck of a stage: the whole stage's gradients are enqueued
-      cb(user, bd.c1.w, chunk_end - bd.c1.w);
+    if (bd.has_ds || last_needed) {  // first bottleneck of a stage (or the last one needed): the stage's gradients are enqueued
+      if (cb && chunk_live) cb(user, bd.c1.w, chunk_end - bd.c1.w);
       chunk_end = bd.c1.w;
+      chunk_live = false;
     }
   }
+  if (lowest >= 0) return MMSA_OK;  // the stem is frozen
   // max-pool, stem BN + ReLU, stem conv (weight gradient only: the image needs none)
   const ConvDef& s = L.stem;
   RET_IF(maxpool_bwd(c.dtype, dOut, ws.pool_idx, t1, B, s.Hout, s.Wout, 64, st));

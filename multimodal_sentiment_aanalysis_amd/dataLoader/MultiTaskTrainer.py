@@ -24,6 +24,7 @@ import torch.optim as optim
 from torch.optim.lr_scheduler import ReduceLROnPlateau
 
 from ..engine import CrossEntropyLoss
+from ..fused import PhaseOptimizer, Plateau
 
 _KEYS = ("loss", "a_loss", "v_loss", "c_loss", "a_acc", "v_acc")
 
@@ -41,7 +42,11 @@ _PHASES = {
 
 
 class MultiTaskTrainer:
-    def __init__(self, model, train_loader, test_loader, device="cuda", test_person=-1):
+    def __init__(self, model, train_loader, test_loader, device="cuda", test_person=-1, hip_optimizer=None):
+        """hip_optimizer: None = on a GPU (the default), the per-phase clip + AdamW run as HIP kernels over the phase's
+        sub-ranges of the flat buffers (fused.PhaseOptimizer); False = torch.optim.AdamW + clip_grad_norm_, literally the
+        reference's objects (works because the parameters are ordinary views)."""
+        self.hip_optimizer = hip_optimizer
         self.model = model.to(device)
         self.train_loader, self.test_loader = train_loader, test_loader
         self.device, self.test_person = device, test_person
@@ -67,14 +72,35 @@ class MultiTaskTrainer:
         for name in unfreeze:
             for p in getattr(self.model, name).parameters():
                 p.requires_grad = True
-        if opt_on is None:
-            params = [p for p in self.model.parameters() if p.requires_grad]
+        state = self._flat_state()
+        if state is not None:  # HIP kernels over the phase's sub-ranges (norm over every trainable module, step on opt_on)
+            trainable = [getattr(self.model, name) for name in unfreeze]
+            owned = trainable if opt_on is None else [getattr(self.model, name) for name in opt_on]
+            opt = PhaseOptimizer(state, owned, trainable, lr=1e-4, weight_decay=1e-4, max_norm=1.0)
+            sched = Plateau(opt, patience=patience, factor=factor)
         else:
-            params = [p for name in opt_on for p in getattr(self.model, name).parameters()]
-        opt = optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
+            if opt_on is None:
+                params = [p for p in self.model.parameters() if p.requires_grad]
+            else:
+                params = [p for name in opt_on for p in getattr(self.model, name).parameters()]
+            opt = optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
+            sched = ReduceLROnPlateau(opt, mode="min", patience=patience, factor=factor)
         setattr(self, slot + "_optimizer", opt)
-        setattr(self, slot + "_scheduler", ReduceLROnPlateau(opt, mode="min", patience=patience, factor=factor))
+        setattr(self, slot + "_scheduler", sched)
         return opt
+
+    def _flat_state(self):
+        """The model's flat parameter state when the HIP optimizer path applies (GPU, engines materialized), else None."""
+        if self.hip_optimizer is False or torch.device(self.device).type != "cuda":
+            return None
+        from ..engine import engines_of, materialize
+        st = getattr(self.model, "_flat_state", None)
+        if st is None or not st.valid():
+            if not engines_of(self.model):
+                return None
+            st = materialize(self.model, torch.device(self.device) if torch.device(self.device).index is not None
+                             else torch.device("cuda", torch.cuda.current_device()))
+        return st
 
     def _setup_phase_EEGnet(self):
         return self._setup("eeg")
@@ -133,7 +159,8 @@ class MultiTaskTrainer:
             else:
                 loss = c_loss = {"c1": c1, "c2": c2, "c3": c3}[objective]
             loss.backward()
-            torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.requires_grad], 1.0)
+            if not isinstance(opt, PhaseOptimizer):  # (the HIP optimizer's step() is clip + AdamW in one)
+                torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.requires_grad], 1.0)
             opt.step()
             self._add(total, labels[0].shape[0], (a_out, v_out), labels, loss, a_loss, v_loss, c_loss)
         return self._record("train", total, len(self.train_loader.dataset))

@@ -175,6 +175,15 @@ class EngineModule(nn.Module):
     def _any_trainable(self):
         return any(p.requires_grad for p in self._pmap.values())
 
+    def _frozen_mask(self):
+        """One byte per parameter-table entry (1 = requires_grad False) for the encoder backwards, or None when everything is
+        trainable: wholly frozen layers / bottlenecks get no weight-gradient kernels and the backward stops below the lowest
+        trainable group (N2: the reference's curriculum phases and fine-tuning freeze sub-graphs)."""
+        flags = [0 if self._pmap[n].requires_grad else 1 for n, _, _ in self._specs]
+        if not any(flags):
+            return None
+        return (ctypes.c_uint8 * len(flags))(*flags)
+
     # ---- gradient-range hook (data parallel) ------------------------------------------------------------------------
     # `_grad_range_hook(eng, offset, length)` (set by FusedTrainStep when world > 1) is called from INSIDE the encoder's
     # backward C call each time the kernels producing grad[offset, offset + length) (engine-relative elements) have been
@@ -346,7 +355,7 @@ class _BertFn(torch.autograd.Function):
         check(_lib.load().mmsa_bert_bwd_cb(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ids),
                                            ptr(ctx.mask), ptr(ctx.ws), ptr(dfeat.contiguous()), ptr(eng._flat_g),
                                            eng._acc_flag(), stream_ptr(), eng._range_cb(), None,
-                                           int(getattr(eng, "layers_per_chunk", 3))), "mmsa_bert_bwd")
+                                           int(getattr(eng, "layers_per_chunk", 3)), eng._frozen_mask()), "mmsa_bert_bwd")
         eng._give_ws(ctx.ws)
         ctx.ws = None
         if getattr(eng, "_grad_ready_hook", None) is not None:
@@ -437,7 +446,7 @@ class _ResnetFn(torch.autograd.Function):
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             check(_lib.load().mmsa_resnet_bwd_cb(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ws),
                                                  ptr(dfeat), ptr(eng._flat_g), eng._acc_flag(), stream_ptr(),
-                                                 eng._range_cb(), None), "mmsa_resnet_bwd")
+                                                 eng._range_cb(), None, eng._frozen_mask()), "mmsa_resnet_bwd")
             if side is not None:
                 dfeat.record_stream(side)
             eng._give_ws(ctx.ws)

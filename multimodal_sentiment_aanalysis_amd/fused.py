@@ -112,18 +112,23 @@ class FlatAdamW:
     device (Trainer.py:74-76 skips the update on a NaN loss): a non-finite gradient norm or loss leaves w, m, v and the bf16
     working copy untouched and does not advance the bias-correction step count (a device int32)."""
 
-    def __init__(self, state, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, ranges=None):
+    def __init__(self, state, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, ranges=None,
+                 norm_ranges=None):
         self.state, self.lr, self.wd, self.betas, self.eps, self.max_norm = state, lr, weight_decay, betas, eps, max_norm
         dev = state.flat_w.device
         n = state.flat_w.numel()
         self.ranges = merge_ranges([(0, n)] if ranges is None else ranges)
+        # the clip norm may span more than the optimizer owns (clip_grad_norm_ over every trainable parameter while the
+        # optimizer steps a subset: MultiTaskTrainer.py:147-177); the extra ranges are scaled in place like torch does
+        self.norm_ranges = self.ranges if norm_ranges is None else merge_ranges(list(norm_ranges) + self.ranges)
+        self.extra_ranges = subtract_ranges(self.norm_ranges, self.ranges)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.steps = torch.zeros(1, dtype=torch.int32, device=dev)  # applied (not skipped) steps
         self.norm_ws = torch.empty(_lib.load().mmsa_grad_norm_ws_bytes(), dtype=torch.uint8, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)  # [total norm, clip coefficient | -1 = skipped]
-        self._offs = (ctypes.c_int64 * len(self.ranges))(*[a for a, _ in self.ranges])
-        self._lens = (ctypes.c_int64 * len(self.ranges))(*[n_ for _, n_ in self.ranges])
+        self._offs = (ctypes.c_int64 * len(self.norm_ranges))(*[a for a, _ in self.norm_ranges])
+        self._lens = (ctypes.c_int64 * len(self.norm_ranges))(*[n_ for _, n_ in self.norm_ranges])
 
     @property
     def t(self):
@@ -133,7 +138,7 @@ class FlatAdamW:
     def step(self, grad_scale=1.0, loss=None):
         L = _lib.load()
         st = self.state
-        check(L.mmsa_grad_norm_ranges(ptr(st.flat_g), self._offs, self._lens, len(self.ranges), grad_scale, self.max_norm,
+        check(L.mmsa_grad_norm_ranges(ptr(st.flat_g), self._offs, self._lens, len(self.norm_ranges), grad_scale, self.max_norm,
                                       ptr(loss), ptr(self.steps), ptr(self.norm_out), ptr(self.norm_ws), stream_ptr()),
               "mmsa_grad_norm_ranges")
         for a, n in self.ranges:
@@ -142,9 +147,98 @@ class FlatAdamW:
                                         ptr(self.v[a:a + n]), ptr(w16), n, self.lr, self.betas[0], self.betas[1], self.eps,
                                         self.wd, ptr(self.steps), ptr(self.norm_out), grad_scale, stream_ptr()),
                   "mmsa_adamw_step_dev")
-        for e, _, _ in st.ranges:
-            if not isinstance(e, HeadEngine):
-                e.mark_weights_fresh()
+        for a, n in self.extra_ranges:
+            check(L.mmsa_grad_scale_clip(ptr(st.flat_g[a:a + n]), n, ptr(self.norm_out), stream_ptr()), "mmsa_grad_scale_clip")
+        if self.ranges == [(0, st.flat_w.numel())]:
+            for e, _, _ in st.ranges:
+                if not isinstance(e, HeadEngine):
+                    e.mark_weights_fresh()  # the whole bf16 working copy was rewritten by this step
+        # (a partial step leaves the engines' version tokens alone: the next forward re-casts the master, which is correct
+        #  for any subset; FlatAdamW bumps the parameters' version counters below so the tokens do change)
+        else:
+            for e, off, n in st.ranges:
+                if any(a < off + n and off < a + ln for a, ln in self.ranges):
+                    e._wt_token = None
+
+
+def subtract_ranges(a, b):
+    """Elements of the (merged) ranges `a` that are in none of the (merged) ranges `b`, as merged ranges."""
+    out = []
+    for s0, n0 in a:
+        cur = s0
+        for s1, n1 in b:
+            if s1 + n1 <= cur or s1 >= s0 + n0:
+                continue
+            if s1 > cur:
+                out.append((cur, s1 - cur))
+            cur = max(cur, s1 + n1)
+        if cur < s0 + n0:
+            out.append((cur, s0 + n0 - cur))
+    return out
+
+
+def module_ranges(state, modules):
+    """Flat-buffer ranges [(offset, length)] of every parameter of `modules`, padded to the 64-element alignment the tables use
+    (the padding holds zeros in w, g, m and v and stays zero under AdamW), merged."""
+    base = state.flat_w.data_ptr()
+    out = []
+    seen = set()
+    for m in modules:
+        for p in m.parameters():
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            off = (p.data_ptr() - base) // 4
+            if 0 <= off < state.flat_w.numel():
+                out.append((off, min((p.numel() + 63) // 64 * 64, state.flat_w.numel() - off)))
+    return merge_ranges(out)
+
+
+class PhaseOptimizer:
+    """What a curriculum phase of the reference's MultiTaskTrainer builds with torch (`optim.AdamW(params, lr=1e-4,
+    weight_decay=1e-4)` + `clip_grad_norm_(model.parameters(), 1.0)`, MultiTaskTrainer.py:55-177,179-467), on the HIP kernels
+    over sub-ranges of the flat buffers: `step()` = clip over `clip_modules` (every trainable parameter) + AdamW on
+    `opt_modules`; `zero_grad()` clears the optimizer's own gradients only — the reference's phase 3 never zeroes the
+    gradients of the modules it unfreezes but does not optimize, they accumulate from batch to batch and enter every norm.
+    `param_groups[0]["lr"]` is live, so a plateau scheduler can drive it."""
+
+    def __init__(self, state, opt_modules, clip_modules, lr=1e-4, weight_decay=1e-4, max_norm=1.0):
+        self.state = state
+        self.opt_ranges = module_ranges(state, opt_modules)
+        self.clip_ranges = module_ranges(state, clip_modules)
+        self.param_groups = [{"lr": lr}]
+        self.adamw = FlatAdamW(state, lr=lr, weight_decay=weight_decay, max_norm=max_norm, ranges=self.opt_ranges,
+                               norm_ranges=self.clip_ranges)
+
+    def zero_grad(self):
+        for a, n in self.opt_ranges:
+            self.state.flat_g[a:a + n].zero_()
+
+    def step(self):
+        self.adamw.lr = self.param_groups[0]["lr"]
+        self.adamw.step()
+
+
+class Plateau:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode="min", threshold=1e-4 relative, cooldown=0, min_lr=0, eps=1e-8) for
+    an optimizer facade with `param_groups` (MultiTaskTrainer.py:70-75,146-151,172-177)."""
+
+    def __init__(self, optimizer, patience, factor):
+        self.optimizer, self.patience, self.factor = optimizer, patience, factor
+        self.best, self.bad = float("inf"), 0
+
+    def step(self, metric):
+        metric = float(metric)
+        if metric < self.best * (1.0 - 1e-4):
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            for g in self.optimizer.param_groups:
+                new = g["lr"] * self.factor
+                if g["lr"] - new > 1e-8:
+                    g["lr"] = new
+            self.bad = 0
 
 
 def merge_ranges(ranges):
@@ -169,11 +263,10 @@ class FusedTrainStep:
         self.opt = FlatAdamW(self.state, lr, weight_decay, betas, eps, max_norm)
         self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if self.world > 1:
-            # A workgroup of the persistent GEMM fills its CU (registers + LDS): a collective's blocks cannot co-reside with
-            # it and would wait for whole CUs, while the GEMM behind them ran a second round of tiles. Leave the collective
-            # 16 of the 256 CUs (2 per XCD) for the whole run; read once by the library at its first GEMM launch.
-            os.environ.setdefault("MMSA_G2_CUS", "240")
+        # (No CU reservation for the collective by default. A workgroup of the persistent GEMM fills its CU, so RCCL's blocks
+        # wait for whole CUs; MMSA_G2_CUS=<n> caps the GEMM grid to leave some free — but the planner's tile counts are exact
+        # multiples of 256 CUs (BERT-base: 768 tiles = 3 rounds), and measured on one MI355X a cap of 248 / 240 / 224 costs
+        # 5.3 % / 5.0 % / 12 % of the WHOLE step, forward included (tools/exp_streams.sh). Left to the env.)
         self.reducer = GradReducer(self.state.flat_g, bucket_bytes) if self.world > 1 else None
         if self.world > 1:  # identical replicas: parameters and BN buffers from rank 0
             dist.broadcast(self.state.flat_w, 0)

@@ -292,8 +292,49 @@ def gen_contrastive():
     npz("n1_contrastive.npz", **out)
 
 
+# ------------------------------------------------------------------------------------------------ N2
+def gen_multitask_phases():
+    """The reference's own MultiTaskTrainer (dataLoader/MultiTaskTrainer.py) CALLED on the identity-encoder fusion head: one
+    epoch of phase 2 (two batches: arousal CE; everything but the valence head trains) and then one epoch of phase 3 (two
+    batches: valence CE; cross-attention, weighting and fusion modules are trainable but only the valence head is handed to
+    the optimizer, so their gradients are never zeroed, keep accumulating, and enter every clip norm), plus evaluate().
+    Stored: inputs, labels, the state_dict before / after each epoch, the epoch metrics — plain arrays."""
+    import importlib.util
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    spec = importlib.util.spec_from_file_location("ref_mtt", "/root/reference/MML_ZYC/dataLoader/MultiTaskTrainer.py")
+    ref_mtt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_mtt)
+    from torch.utils.data import DataLoader, TensorDataset
+    m = ref_head_model(6)
+    n, bs = 32, 16
+    feats = [rnd(n, 256, seed=170 + i) for i in range(3)]
+    arousal = torch.randint(0, 3, (n,), generator=torch.Generator().manual_seed(173))
+    valence = torch.randint(0, 3, (n,), generator=torch.Generator().manual_seed(174))
+    ds = TensorDataset(feats[0], feats[1], feats[2], arousal, valence)
+    train, test = DataLoader(ds, batch_size=bs, shuffle=False), DataLoader(ds, batch_size=bs, shuffle=False)
+    arrays = {"w0." + k: v.clone() for k, v in m.state_dict().items()}
+    tr = ref_mtt.MultiTaskTrainer(m, train, test, device="cpu")
+    r2 = tr.train_epoch_phase2(1)
+    arrays.update({"w_p2." + k: v.clone() for k, v in m.state_dict().items()})
+    e2 = tr.evaluate()
+    m.train()
+    r3 = tr.train_epoch_phase3(1)
+    arrays.update({"w_p3." + k: v.clone() for k, v in m.state_dict().items()})
+    e3 = tr.evaluate()
+    for tag, r in (("train_p2", r2), ("eval_p2", e2), ("train_p3", r3), ("eval_p3", e3)):
+        for k, v in r.items():
+            arrays[f"{tag}.{k}"] = torch.tensor(float(v), dtype=torch.float64)
+    # which tensors each phase's optimizer owned / which were trainable (for the test's bookkeeping checks)
+    moved2 = [k for k in m.state_dict() if not torch.equal(arrays["w0." + k], arrays["w_p2." + k]) and "running" not in k and "num_batches" not in k]
+    moved3 = [k for k in m.state_dict() if not torch.equal(arrays["w_p2." + k], arrays["w_p3." + k]) and "running" not in k and "num_batches" not in k]
+    print("phase 2 moved", len(moved2), "tensors; phase 3 moved", len(moved3), ":", sorted({k.split('.')[0] for k in moved3}))
+    npz("n2_multitask_phases.npz", arousal=arousal, valence=valence, **{f"f{i}": feats[i] for i in range(3)}, **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["a1", "a2", "a4", "a5", "a7", "e1", "n1"]
+    which = sys.argv[1:] or ["a1", "a2", "a4", "a5", "a7", "e1", "n1", "n2"]
+    if "n2" in which:
+        gen_multitask_phases()
     if "n1" in which:
         gen_contrastive()
     if "a1" in which:

@@ -326,6 +326,89 @@ def test_n1_multitask_forward_returns_contrastive_terms(dev):
     assert m.contrastive_weight.grad is not None
 
 
+class _RefHeadMT(_RefHead):
+    """_RefHead with the reference model's MultiTaskTrainer contract (MultimodalModel.py:262-322): identity encoder slots
+    under the reference's attribute names, `(arousal, valence, c1, c2, c3) = model(eeg, eye, pps, labels=(a, v))`."""
+
+    def __init__(self):
+        super().__init__(valence=True)
+        import torch.nn as nn
+        self.eeg_net, self.eye_net, self.pps_net = nn.Identity(), nn.Identity(), nn.Identity()
+        self.contrastive_weight = nn.Parameter(torch.ones(1))
+        self.temperature = nn.Parameter(torch.tensor(0.01))
+
+    def forward(self, eeg, eye, pps, labels=None):
+        from multimodal_sentiment_aanalysis_amd.engine import supervised_infonce
+        outs = super().forward(eeg, eye, pps)
+        if labels is None:
+            return outs[0], outs[2]
+        c = [self.contrastive_weight * supervised_infonce(f, f, labels[0], self.temperature) for f in (eeg, eye, pps)]
+        return outs[0], outs[2], c[0], c[1], c[2]
+
+
+@pytest.mark.parametrize("hip_optimizer", [True, False])
+def test_n2_multitask_phases_against_reference(dev, hip_optimizer):
+    """N2 pinned on the reference's OWN MultiTaskTrainer (tests/golden/make_golden.py::gen_multitask_phases calls it on the
+    identity-encoder fusion head): one epoch of phase 2 and one of phase 3, two batches each, then evaluate(). Phase 3 is the
+    tricky one: cross-attention / weighting / fusion modules are trainable but not handed to the optimizer, so their gradients
+    are never zeroed, accumulate across batches (scaled in place by every clip) and enter every clip norm, while only the
+    valence head moves. hip_optimizer=True: clip + AdamW as HIP kernels over the phase's sub-ranges of the flat buffers
+    (fused.PhaseOptimizer); False: torch.optim.AdamW on the same parameter views."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from multimodal_sentiment_aanalysis_amd.dataLoader import MultiTaskTrainer
+    from multimodal_sentiment_aanalysis_amd.fused import PhaseOptimizer
+    d = load("n2_multitask_phases.npz")
+    m = _RefHeadMT()
+    missing = m.load_state_dict(sub(d, "w0."), strict=False)
+    assert not missing.missing_keys, missing
+    ds = TensorDataset(d["f0"], d["f1"], d["f2"], d["arousal"], d["valence"])
+    loader = DataLoader(ds, batch_size=16, shuffle=False)
+
+    class FeatTrainer(MultiTaskTrainer):
+        def _feeds(self, batch):  # the three "modalities" are feature vectors here (identity encoder slots)
+            x1, x2, x3, a, v = batch
+            return (x1.to(self.device).float(), x2.to(self.device).float(), x3.to(self.device).float()), (a.to(self.device), v.to(self.device))
+
+    tr = FeatTrainer(m, loader, loader, device=dev, hip_optimizer=hip_optimizer)
+
+    def check_state(tag, steps):
+        sd = m.state_dict()
+        for k, ref in sub(d, tag).items():
+            if "num_batches" in k:
+                assert int(sd[k]) == int(ref), k
+                continue
+            diff = (sd[k].detach().cpu().double() - ref.double()).abs().max().item()
+            # an AdamW step moves every element by ~lr = 1e-4 (first steps: update = +-lr whatever the gradient's size), so a
+            # gradient element within rounding of 0 may step the other way: bound = 2.2 lr per step taken, as in A7
+            assert diff <= 2.2e-4 * steps + 1e-6 * ref.abs().max().item(), f"{tag}{k}: {diff:.3e}"
+
+    def check_metrics(tag, got):
+        for k, v in got.items():
+            ref = float(d[f"{tag}.{k}"])
+            assert abs(v - ref) <= 2e-4 * max(1.0, abs(ref)), f"{tag}.{k}: {v} vs {ref}"
+
+    r2 = tr.train_epoch_phase2(1)
+    assert isinstance(tr.phase2_optimizer, PhaseOptimizer) == hip_optimizer
+    check_metrics("train_p2", r2)
+    check_state("w_p2.", 2)
+    check_metrics("eval_p2", tr.evaluate())
+    m.train()
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    r3 = tr.train_epoch_phase3(1)
+    check_metrics("train_p3", r3)
+    check_state("w_p3.", 4)
+    moved = {k for k, v in m.named_parameters() if not torch.equal(v.detach(), before[k])}
+    assert moved and all(k.startswith("valence_head.") for k in moved), sorted(moved)[:5]
+    # tight check of what phase 3 moved (the accumulate-and-rescale quirk changes its clip coefficient on the 2nd batch)
+    for k in moved:
+        ref = d["w_p3." + k]
+        delta_ref = (ref - d["w_p2." + k]).double()
+        delta = (m.state_dict()[k].detach().cpu() - d["w_p2." + k]).double()
+        if delta_ref.abs().max() > 0:
+            assert (delta - delta_ref).norm() <= 0.05 * delta_ref.norm() + 1e-7, k
+    check_metrics("eval_p3", tr.evaluate())
+
+
 def test_n2_multitask_trainer_phases(dev, tmp_path, monkeypatch):
     """N2: the reference's five-phase MultiTaskTrainer surface on the HIP modules — each phase moves exactly the parameters
     its optimizer owns (frozen sub-graphs stay bit-identical), metrics have the reference's keys, run() walks all phases."""
