@@ -728,3 +728,48 @@ def test_working_copy_follows_any_parameter_edit(dev):
         p.mul_(1.5)
         b = net(ids.to(dev), mask.to(dev)).clone()
     assert not torch.equal(a, b), "stale bf16 working copy after an in-place edit of one mid-layer tensor"
+
+
+@pytest.mark.parametrize("which", ["bert", "resnet"])
+def test_frozen_groups_skip_kernels_and_keep_gradients(dev, which):
+    """N2 inside an encoder: with the lower layers (BERT: embeddings + layer 0; ResNet: stem + the first two bottlenecks) frozen,
+    the backward launches fewer matrix-core GEMMs (no weight gradients for frozen groups, no data gradient below the lowest
+    trainable one), the trainable parameters get EXACTLY the gradients of the all-trainable run, and frozen ones get none."""
+    image, ids, mask, _ = synth_batch(4, 32, 96, 96, MINI_BERT["vocab"], seed=11)
+    wgt = torch.randn(4, 256, generator=torch.Generator().manual_seed(9)).to(dev)
+    L = _lib.load()
+
+    def run(freeze):
+        torch.manual_seed(0)
+        if which == "bert":
+            net = BertTextNet(dict(MINI_BERT, layers=3))
+            frozen = lambda n: n.startswith("bert.embeddings.") or n.startswith("bert.encoder.layer.0.")  # noqa: E731
+            fwd = lambda: net(ids.to(dev), mask.to(dev))  # noqa: E731
+        else:
+            net = ResNetImageNet(MINI_RESNET2)
+            frozen = lambda n: n.startswith(("resnet.conv1.", "resnet.bn1.", "resnet.layer1.0.", "resnet.layer1.1."))  # noqa: E731
+            fwd = lambda: net(image.to(dev))  # noqa: E731
+        net.precision = "bf16"
+        net.to(dev)
+        net.train()
+        if freeze:
+            for n, p in net.named_parameters():
+                if frozen(n):
+                    p.requires_grad = False
+        out = fwd()
+        L.mmsa_prof_mode(0)
+        L.mmsa_prof_begin(4096)
+        (out * wgt).sum().backward()
+        torch.cuda.synchronize()
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        L.mmsa_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+        return {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in net.named_parameters()}, n.value, frozen
+
+    g_all, n_all, frozen = run(False)
+    g_fr, n_fr, _ = run(True)
+    assert n_fr < n_all, f"{which}: {n_fr} GEMM launches with frozen groups vs {n_all}"
+    for k, g in g_all.items():
+        if frozen(k):
+            assert g_fr[k] is None, k
+        else:
+            assert g_fr[k] is not None and torch.equal(g_fr[k], g), f"{which}: gradient of trainable {k} changed"
