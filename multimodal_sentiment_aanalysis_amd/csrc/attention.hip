@@ -14,6 +14,7 @@
 //
 // SIMT kernels (fp32 or bf16 storage): 4 lanes per query/key, each owning 16 of the 64 head dims. They are the
 // exact-fp32 execution mode and the on-device cross-check of the MFMA kernels.
+#include <stdlib.h>
 #include "common.h"
 #include "ops.h"
 
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ MFMA backward
-// 512 threads = 8 waves; wave w owns queries [16w, 16w+16) in phase 1 and keys [16w, 16w+16) in phase 2 (S <= 128).
+// 512 threads = 8 waves; wave w owns queries [16w, 16w+16) in phase 1 and keys [16w, 16w+16) in phase 2 (S <= 128;
+// longer sequences: attn_bwd_mfma_rc_kernel below).
 template <int NT>
 __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask,
                                                             const bf16* __restrict__ dctx, bf16* __restrict__ dqkv, int heads,
@@ -300,6 +302,189 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const bf16* __restri
         const bf16x8 qf = tr_pair(Qt, img_off(row0, col), img_off(row1, col));
         dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[dt], 0, 0, 0);
         dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, sf, dk[dt], 0, 0, 0);
+      }
+    }
+    bf16* krow = dqkv + ((long)b * S + k0 + r16) * ld + Hd + h * HD;
+    bf16* vrow = krow + Hd;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 kv = {(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
+      bf16x4 vv = {(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
+      *(bf16x4*)(krow + 16 * dt + 4 * g) = kv;
+      *(bf16x4*)(vrow + 16 * dt + 4 * g) = vv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ MFMA backward, S <= 256
+// The kernel above keeps P and dS as two [S][S] bf16 LDS images for its key-owned phase: 2 * S * S * 2 bytes = 256 KiB at
+// S = 256 (BERT-large, BASELINE.json configs[3]) — more than the CU has. This variant keeps NO S x S image: phase 1 (a wave
+// owns 16 queries at a time: full-row scores in registers, softmax statistics, dQ) leaves three floats per query in LDS — row
+// maximum, 1 / row sum, delta = sum_key P dP — and phase 2 (a wave owns 16 keys at a time) RECOMPUTES the transposed score and
+// dP tiles two query tiles at a time from the Q / dO / K / V images (rows = queries, lane = key column), turns them into P^T
+// and dS^T with those statistics, and feeds them straight into the dV / dK products as B-slot operands (the accumulator-as-
+// operand order: element j of lane group g is query 32 ks + 4 g + j (j < 4) or 32 ks + 16 + 4 g + j - 4, matched by the
+// transposed dO / Q reads, exactly as the forward does for P V). Cost: the two S x S x 64 products are done twice (+50 % of
+// this kernel's MFMAs, attention being 2.7 % of the model's); LDS: four [S][64] images = 128 KiB at S = 256.
+// 512 threads = 8 waves; NT = S / 16 (even) query / key tiles are dealt round-robin to the waves.
+template <int NT>
+__global__ __launch_bounds__(512) void attn_bwd_mfma_rc_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask,
+                                                               const bf16* __restrict__ dctx, bf16* __restrict__ dqkv, int heads,
+                                                               float scale) {
+  constexpr int S = NT * 16;
+  static_assert(NT % 2 == 0 && NT <= MAX_TILES, "even tile count, S <= 256");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int Hd = heads * HD, ld = 3 * Hd;
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4, qq = r16 >> 2, pp = r16 & 3;
+  unsigned char* Kt = smem;
+  unsigned char* Vt = Kt + S * 128;
+  unsigned char* Qt = Vt + S * 128;
+  unsigned char* Dt = Qt + S * 128;
+  float* mb = (float*)(Dt + S * 128);
+  float* rmx = mb + S;     // row maximum of the scaled, masked scores
+  float* rinv = rmx + S;   // 1 / sum exp(score - max)
+  float* rdel = rinv + S;  // delta = sum_key P dP
+  const bf16* base = qkv + (long)b * S * ld + h * HD;
+  const bf16* dbase = dctx + (long)b * S * Hd + h * HD;
+  stage_rows(Qt, base, ld, S, tid, 512);
+  stage_rows(Kt, base + Hd, ld, S, tid, 512);
+  stage_rows(Vt, base + 2 * Hd, ld, S, tid, 512);
+  stage_rows(Dt, dbase, Hd, S, tid, 512);
+  for (int i = tid; i < S; i += 512) mb[i] = (mask == nullptr || mask[(long)b * S + i] != 0.f) ? 0.f : 1.f;
+  __syncthreads();
+
+  // ---- phase 1: query-owned. lane: query q0 + r16, keys 16 t + 4 g + r
+  for (int qt = wave; qt < NT; qt += 8) {
+    const int q0 = qt * 16;
+    bf16x8 qf[2], df[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      qf[kk] = *(const bf16x8*)(Qt + img_off(q0 + r16, kk * 32 + 8 * g));
+      df[kk] = *(const bf16x8*)(Dt + img_off(q0 + r16, kk * 32 + 8 * g));
+    }
+    f32x4 s[NT], dp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s[t] = f32x4{0, 0, 0, 0};
+      dp[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 kf = *(const bf16x8*)(Kt + img_off(16 * t + r16, kk * 32 + 8 * g));
+        const bf16x8 vf = *(const bf16x8*)(Vt + img_off(16 * t + r16, kk * 32 + 8 * g));
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df[kk], dp[t], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = mb[16 * t + 4 * g + r] != 0.f ? MASK_NEG : s[t][r] * scale;
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[t][r] - mx);
+        s[t][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    float delta = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[t][r] = (float)(bf16)(s[t][r] * inv);  // the forward multiplies V by the bf16-rounded probability
+        delta += s[t][r] * dp[t][r];
+      }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    if (g == 0) { rmx[q0 + r16] = mx; rinv[q0 + r16] = inv; rdel[q0 + r16] = delta; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dp[t][r] = s[t][r] * (dp[t][r] - delta) * scale;  // dS (fp32)
+    // dQ[q][d] = sum_key dS[q][key] K[key][d]
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < NT / 2; ++ks) {
+      const bf16x8 pf = pack_bf16x8(dp[2 * ks], dp[2 * ks + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int col = 16 * dt + 4 * pp;
+        const bf16x8 kf = tr_pair(Kt, img_off(32 * ks + 4 * g + qq, col), img_off(32 * ks + 16 + 4 * g + qq, col));
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, pf, o[dt], 0, 0, 0);
+      }
+    }
+    bf16* orow = dqkv + ((long)b * S + q0 + r16) * ld + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 v = {(bf16)o[dt][0], (bf16)o[dt][1], (bf16)o[dt][2], (bf16)o[dt][3]};
+      *(bf16x4*)(orow + 16 * dt + 4 * g) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: key-owned. lane: key k0 + r16, queries 16 t + 4 g + r (rows of the recomputed transposed tiles)
+  for (int kt = wave; kt < NT; kt += 8) {
+    const int k0 = kt * 16;
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      kf[kk] = *(const bf16x8*)(Kt + img_off(k0 + r16, kk * 32 + 8 * g));
+      vf[kk] = *(const bf16x8*)(Vt + img_off(k0 + r16, kk * 32 + 8 * g));
+    }
+    const bool masked = mb[k0 + r16] != 0.f;
+    f32x4 dv[4], dk[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dv[dt] = f32x4{0, 0, 0, 0}; dk[dt] = f32x4{0, 0, 0, 0}; }
+#pragma unroll 2
+    for (int ks = 0; ks < NT / 2; ++ks) {
+      f32x4 pT[2], sT[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * ks + u;
+        f32x4 sc = {0, 0, 0, 0}, dpv = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 qf = *(const bf16x8*)(Qt + img_off(16 * t + r16, kk * 32 + 8 * g));
+          const bf16x8 df = *(const bf16x8*)(Dt + img_off(16 * t + r16, kk * 32 + 8 * g));
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[kk], sc, 0, 0, 0);    // [query 16t + 4g + r][key k0 + r16]
+          dpv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[kk], dpv, 0, 0, 0);  // dP = dO V^T, same layout
+        }
+        const f32x4 mx4 = *(const f32x4*)(rmx + 16 * t + 4 * g);
+        const f32x4 in4 = *(const f32x4*)(rinv + 16 * t + 4 * g);
+        const f32x4 de4 = *(const f32x4*)(rdel + 16 * t + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = masked ? MASK_NEG : sc[r] * scale;
+          const float p = (float)(bf16)(__expf(v - mx4[r]) * in4[r]);
+          pT[u][r] = p;
+          sT[u][r] = p * (dpv[r] - de4[r]) * scale;
+        }
+      }
+      const bf16x8 pf = pack_bf16x8(pT[0], pT[1]);
+      const bf16x8 sf = pack_bf16x8(sT[0], sT[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int col = 16 * dt + 4 * pp;
+        const bf16x8 dof = tr_pair(Dt, img_off(32 * ks + 4 * g + qq, col), img_off(32 * ks + 16 + 4 * g + qq, col));
+        const bf16x8 qtf = tr_pair(Qt, img_off(32 * ks + 4 * g + qq, col), img_off(32 * ks + 16 + 4 * g + qq, col));
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[dt], 0, 0, 0);  // dV[key][d] += sum_q P[q][key] dO[q][d]
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, sf, dk[dt], 0, 0, 0);  // dK[key][d] += sum_q dS[q][key] Q[q][d]
       }
     }
     bf16* krow = dqkv + ((long)b * S + k0 + r16) * ld + Hd + h * HD;
@@ -535,6 +720,22 @@ static int attn_bwd_mfma_nt(const void* qkv, const float* mask, const void* dctx
   return MMSA_OK;
 }
 
+template <int NT>
+static int attn_bwd_mfma_rc_nt(const void* qkv, const float* mask, const void* dctx, void* dqkv, int B, int heads,
+                               hipStream_t st) {
+  constexpr int S = NT * 16;
+  const size_t lds = (size_t)4 * S * 128 + (size_t)4 * S * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_rc_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_mfma_rc_kernel<NT>, dim3(B * heads), dim3(512), lds, st, (const bf16*)qkv, mask,
+                     (const bf16*)dctx, (bf16*)dqkv, heads, 0.125f);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
 // impl: 0 = fp32 storage (SIMT), 1 = bf16 storage MFMA, 2 = bf16 storage SIMT (cross-check)
 int attention_fwd(int impl, const void* qkv, const float* mask, void* ctx, int B, int S, int heads, int head_dim,
                   hipStream_t st) {
@@ -564,7 +765,13 @@ int attention_bwd(int impl, const void* qkv, const float* mask, const void* dctx
     case 16: return attn_bwd_mfma_nt<1>(qkv, mask, dctx, dqkv, B, heads, st);
     case 32: return attn_bwd_mfma_nt<2>(qkv, mask, dctx, dqkv, B, heads, st);
     case 64: return attn_bwd_mfma_nt<4>(qkv, mask, dctx, dqkv, B, heads, st);
-    case 128: return attn_bwd_mfma_nt<8>(qkv, mask, dctx, dqkv, B, heads, st);
+    case 128: {  // MMSA_ATTN_BWD_RC=1: the recompute variant at S = 128 too (A/B hook)
+      static const bool rc = [] { const char* v = getenv("MMSA_ATTN_BWD_RC"); return v && atoi(v) != 0; }();
+      return rc ? attn_bwd_mfma_rc_nt<8>(qkv, mask, dctx, dqkv, B, heads, st)
+                : attn_bwd_mfma_nt<8>(qkv, mask, dctx, dqkv, B, heads, st);
+    }
+    case 192: return attn_bwd_mfma_rc_nt<12>(qkv, mask, dctx, dqkv, B, heads, st);
+    case 256: return attn_bwd_mfma_rc_nt<16>(qkv, mask, dctx, dqkv, B, heads, st);  // BERT-large S = 256 (configs[3])
     default: return attn_bwd_simt<bf16>(qkv, mask, dctx, dqkv, ws, B, S, heads, st);
   }
 }

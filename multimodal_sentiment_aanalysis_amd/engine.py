@@ -697,11 +697,68 @@ class SupConFn(torch.autograd.Function):
         return d1 * g, d2 * g, None, None
 
 
-def supervised_infonce(feat1, feat2, labels, temperature):
-    """loss = InfoNCE(feat1, feat2 | labels, temperature) — MultimodalModel.py:232-260 on the fused kernel."""
+class _GatherRows(torch.autograd.Function):
+    """Data-parallel contrastive terms: the rows of every rank, concatenated in rank order, so that the
+    negatives of an anchor are the whole GLOBAL batch, as in the reference's single process (MultimodalModel.py:232-260,
+    train.py:16-40). Forward: all-gather (RCCL over xGMI; gloo in the CPU tests). Every rank then computes the same global loss,
+    so the gradient of that loss w.r.t. this rank's rows is its slice of the full gradient — no collective in the backward —
+    times world_size, because the trainer averages parameter gradients over ranks (sum / world) and each rank contributes only
+    the part that flows through its own rows."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        x = x.contiguous()
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x, group=group)
+        ctx.world, ctx.rank, ctx.rows = world, rank, x.shape[0]
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        a = ctx.rank * ctx.rows
+        return g[a:a + ctx.rows] * float(ctx.world), None
+
+
+def global_rows(x, group=None):
+    """x [B, ...] on every rank -> [world * B, ...] in rank order (identity without an initialised process group). Differentiable
+    for floating-point inputs; labels (integers) are gathered without a graph."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return x
+    if x.is_floating_point() and x.requires_grad:
+        return _GatherRows.apply(x, group)
+    x = x.contiguous()
+    parts = [torch.empty_like(x) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, x, group=group)
+    return torch.cat(parts, 0)
+
+
+def supervised_infonce(feat1, feat2, labels, temperature, global_negatives=True):
+    """loss = InfoNCE(feat1, feat2 | labels, temperature) — MultimodalModel.py:232-260 on the fused kernel. Under data parallelism
+    the features and labels of all ranks are gathered first (global_negatives), so the loss is that of the global batch."""
+    if global_negatives:
+        same = feat1 is feat2
+        feat1 = global_rows(feat1)
+        feat2 = feat1 if same else global_rows(feat2)
+        labels = global_rows(labels)
     return InfoNCEFn.apply(feat1, feat2, labels, temperature)
 
 
-def supcon_loss(z1, z2, labels, temperature=0.1):
-    """train.py:16-40 on the fused kernel."""
+def supcon_loss(z1, z2, labels, temperature=0.1, global_negatives=True):
+    """train.py:16-40 on the fused kernel (two views; global batch under data parallelism)."""
+    if global_negatives:
+        z1, z2, labels = global_rows(z1), global_rows(z2), global_rows(labels)
+    return SupConFn.apply(z1, z2, labels, temperature)
+
+
+def nt_xent_loss(z1, z2, temperature=0.5, global_negatives=True):
+    """The label-free NT-Xent of the reference's ME-MHACL script (ME-MHACL/train.py:47-66): cross-entropy of the [2B, 2B] cosine
+    similarity / T with the diagonal masked out, target = the other view of the same sample. That is the two-view supervised
+    contrastive loss (train.py:16-40) with every sample its own class — one positive per anchor — so it runs on the same fused
+    kernel with labels = arange(B); the two differ only by train.py's +1e-8 guards (below fp32 resolution of the terms here)."""
+    if global_negatives:
+        z1, z2 = global_rows(z1), global_rows(z2)
+    labels = torch.arange(z1.shape[0], device=z1.device)
     return SupConFn.apply(z1, z2, labels, temperature)

@@ -7,7 +7,7 @@ This file is host code, like the reference's."""
 import torch
 import torch.optim as optim
 
-from .engine import CrossEntropyLoss, supcon_loss
+from .engine import CrossEntropyLoss, nt_xent_loss, supcon_loss  # noqa: F401  (nt_xent_loss: ME-MHACL/train.py:47-66)
 
 
 def contrastive_loss(z1, z2, labels, temperature=0.1):

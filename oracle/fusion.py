@@ -190,3 +190,16 @@ def supcon_two_view(z1, z2, labels, temperature=0.1):
     denom = torch.exp(sim).masked_fill(eye, 0.0).sum(dim=1, keepdim=True)
     log_prob = sim - torch.log(denom + 1e-8)
     return (-(mask * log_prob).sum(dim=1) / (mask.sum(dim=1) + 1e-8)).mean()
+
+
+def nt_xent(z1, z2, temperature):
+    """NT-Xent of the reference's ME-MHACL script (MML_ZYC/ME-MHACL/train.py:47-66): z = normalize(cat(z1, z2)); sim = z z^T with
+    the diagonal filled with -9e15, divided by T; loss = CE(sim, partner index). (That file is a script — its loss function
+    cannot be imported without running its data loading — so this restatement is pinned by reading only.)"""
+    import torch.nn.functional as F
+    B = z1.shape[0]
+    z = F.normalize(torch.cat([z1, z2], 0), dim=1)
+    sim = z @ z.t()
+    sim = sim.masked_fill(torch.eye(2 * B, dtype=torch.bool), -9e15) / temperature
+    targets = torch.cat([torch.arange(B, 2 * B), torch.arange(0, B)])
+    return F.cross_entropy(sim, targets)

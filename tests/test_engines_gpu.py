@@ -63,7 +63,7 @@ def _check_grads(got, ref, tol, what, skip=(), l2=False):
 
 @pytest.mark.parametrize("precision,pol,tol_f,tol_g", [("fp32", FP32, 2e-5, 2e-4), ("bf16", BF16G, 2e-2, 6e-2)])
 # S = 128 is the benchmark sequence length (MFMA attention both ways); S = 256 is BASELINE.json configs[3]
-# (MFMA attention forward, the backward falls back to the SIMT kernel)
+# (MFMA attention both ways: the backward is the recompute variant that keeps no S x S image in LDS)
 @pytest.mark.parametrize("B,S,masked", [(4, 32, False), (3, 16, True), (2, 64, True), (2, 128, True), (1, 256, False)])
 def test_bert_engine(dev, precision, pol, tol_f, tol_g, B, S, masked):
     torch.manual_seed(0)
@@ -581,13 +581,15 @@ def test_full_size_resnet50_mfma_vs_simt_forward(dev):
     assert rel_err(outs[0], outs[1]) < 2e-2, f"ResNet-50 features MFMA vs SIMT {rel_err(outs[0], outs[1])}"
 
 
-def test_full_size_train_step_properties(dev):
-    """The benchmark's model (BERT-base + ResNet-50 + fusion head, bf16) at B = 16: properties that need no oracle.
+@pytest.mark.parametrize("B", [16, 64])
+def test_full_size_train_step_properties(dev, B):
+    """The benchmark's model (BERT-base + ResNet-50 + fusion head, bf16) at B = 16 and at B = 64 (BASELINE.json configs[1]'s
+    own per-GPU batch: every planner decision, tile shape and K split of the benchmarked step): properties that need no oracle.
     (1) the loss of a fixed batch goes down over optimizer steps; (2) a second run from the same seed reproduces the
     first loss exactly (the forward has no atomics) and the later ones closely (every reduction is order-fixed except
     the word-embedding scatter, whose fp32 atomics reorder the sums of repeated tokens)."""
     from multimodal_sentiment_aanalysis_amd.fused import FusedTrainStep
-    image, ids, mask, labels = synth_batch(16, 128, 224, 224, 30522, seed=5)
+    image, ids, mask, labels = synth_batch(B, 128, 224, 224, 30522, seed=5)
     batch = (image.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
 
     def run():
@@ -612,9 +614,10 @@ def test_full_size_train_step_properties(dev):
 
 def test_c3_bert_large_resnet101_train_steps(dev):
     """BASELINE.json configs[3] (BERT-large S = 256 + ResNet-101): the largest configuration runs through the same engines
-    (attention backward at S = 256 uses the blocked SIMT kernel) — a fixed batch's loss is finite and goes down."""
+    (attention backward at S = 256: the recompute MFMA kernel) at its stated per-GPU batch of 32 — a fixed batch's loss is
+    finite and goes down."""
     from multimodal_sentiment_aanalysis_amd.fused import FusedTrainStep
-    image, ids, mask, labels = synth_batch(4, 256, 224, 224, 30522, seed=9)
+    image, ids, mask, labels = synth_batch(32, 256, 224, 224, 30522, seed=9)
     batch = (image.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
     torch.manual_seed(0)
     model = mm.MultimodalTransformerModel(bert_config=mm.BERT_LARGE, resnet_config=mm.RESNET101, dropout=0.0)

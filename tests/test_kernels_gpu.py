@@ -242,7 +242,9 @@ def attn_ref(qkv, mask, dctx, B, S, heads):
 
 @pytest.mark.parametrize("impl,dtype", IMPLS[:3])  # attention: fp32 SIMT, bf16 MFMA, bf16 SIMT (no GEMM-only impls)
 @pytest.mark.parametrize("B,S,heads,masked", [(2, 128, 2, False), (3, 32, 4, True), (2, 64, 1, True), (1, 16, 2, False),
-                                              (2, 48, 2, True), (1, 256, 1, False)])
+                                              (2, 48, 2, True), (1, 256, 1, False),
+                                              # S > 128: the MFMA backward is the recompute variant (attn_bwd_mfma_rc_kernel)
+                                              (2, 256, 2, True), (1, 192, 2, True), (3, 256, 4, False)])
 def test_attention(dev, impl, dtype, B, S, heads, masked):
     Hd = heads * 64
     qkv = rnd((B * S, 3 * Hd), dtype, dev, 1)
