@@ -591,3 +591,23 @@ def test_c0_full_size_bf16(dev, fname):
         assert m[k] < 2.0 * pol[k] + floor, (k, m[k], pol[k])
     # the loss is 1-Lipschitz in the logits (mean CE): bounded by the logit distance, whatever sign pattern the draw has
     assert m["dloss"] < max(2.0 * pol["dloss"], pol["dlogits"]) + 1e-2, (m["dloss"], pol)
+
+
+def test_n1_nt_xent_variant(dev):
+    """The label-free NT-Xent of the reference's ME-MHACL script (ME-MHACL/train.py:47-66) = the two-view kernel with every
+    sample its own class; against the oracle's restatement (that file is a script: pinned by reading) and its autograd."""
+    from multimodal_sentiment_aanalysis_amd.engine import nt_xent_loss
+    from oracle import fusion as OF
+    for B, D, T in ((16, 128, 0.5), (64, 128, 0.1), (5, 32, 0.5)):
+        g = torch.Generator().manual_seed(B)
+        z1, z2 = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
+        a, b = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+        ref = OF.nt_xent(a, b, T)
+        ref.backward()
+        x, y = z1.to(dev).requires_grad_(True), z2.to(dev).requires_grad_(True)
+        loss = nt_xent_loss(x, y, T)
+        loss.backward()
+        assert abs(loss.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item())), (B, loss.item(), ref.item())
+        scale = max(a.grad.abs().max().item(), b.grad.abs().max().item())
+        assert (x.grad.cpu() - a.grad).abs().max().item() < 1e-4 * scale
+        assert (y.grad.cpu() - b.grad).abs().max().item() < 1e-4 * scale
