@@ -6,6 +6,7 @@
 //
 // Semantics follow nn.BatchNorm1d/2d as the reference uses them (MultimodalModel.py:181,186,194,380,419,423;
 // eps 1e-5, momentum 0.1): normalise with the biased batch variance, update running_var with the unbiased one.
+#include <stdlib.h>
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "ops.h"
@@ -329,6 +330,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// Minimum rows a lane walks in the partial-sum kernels. 16 left the mid-size layers with 49-392 workgroups for 256 CUs
+// (C = 64 at 200704 rows: 392; C = 256 at 12544 rows: 98): 4 gives every layer >= 4x as many chunks (up to the 1024 cap).
+// MMSA_BN_RPL overrides (A/B hook).
+static int bn_rows_per_lane() {
+  static const int v = [] { const char* e = getenv("MMSA_BN_RPL"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 4; }();
+  return v;
+}
+
 size_t bn_ws_bytes(int C) { return ((size_t)BN_CHUNKS * 2 * C + 2 * C) * sizeof(float); }
 
 template <typename T>
@@ -337,7 +346,7 @@ static int bn_forward_t(const T* x, const float* gamma, const float* beta, float
                         int act, int training, hipStream_t st, unsigned char* mask) {
   const BnMap m = bn_map(C);
   if (training) {
-    const int rpc = max(cdiv(M, BN_CHUNKS), m.rlanes * 16);
+    const int rpc = max(cdiv(M, BN_CHUNKS), m.rlanes * bn_rows_per_lane());
     const int chunks = cdiv(M, rpc);
     hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(chunks, m.cgroups), dim3(256), 0, st, x, ws, M, C, m.cthreads, rpc);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, BN_FIN_COLS)), dim3(256), 0, st, (const float*)ws, chunks, M, C, eps,
@@ -371,7 +380,7 @@ static int bn_backward_t(const T* dy, const T* x, const T* y, const float* mean,
                          const float* beta, T* dx, T* dres, float* dgamma, float* dbeta, int accumulate, float* ws, int M,
                          int C, int act, int training, hipStream_t st, const unsigned char* mask) {
   const BnMap m = bn_map(C);
-  const int rpc = max(cdiv(M, BN_CHUNKS), m.rlanes * 16);
+  const int rpc = max(cdiv(M, BN_CHUNKS), m.rlanes * bn_rows_per_lane());
   const int chunks = cdiv(M, rpc);
   float* sums = ws + (size_t)BN_CHUNKS * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(chunks, m.cgroups), dim3(256), 0, st, dy, x, y, mean, invstd, gamma,
