@@ -327,7 +327,8 @@ def main(argv=None):
         gemm_tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         gemm_tflops_ev = fl_ev.value / (ms_ev.value * 1e-3) / 1e12 if ms_ev.value > 0 else 0.0
         step_tflops = pairs * flop_mult * fwd_gflop / dt / 1e3 / world
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src = pmc_traffic() if (args.model == "base" and args.mode == "train" and args.precision == "bf16"
+                                                 and args.batch == 64 and args.seq == 128) else (None, None)
         names = {"base": "BERT-base S=%d + ResNet-50 224x224", "large": "BERT-large S=%d + ResNet-101 224x224"}
         what = ("train step (fwd+CE+bwd+grad all-reduce+clip+AdamW)" if args.mode == "train" else
                 "forward only (training-mode BatchNorm, no autograd)")
@@ -351,7 +352,7 @@ def main(argv=None):
                          "note": "value / ms_per_step = the FIRST region after the warm-up (max over ranks)"},
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_GEMM_LAUNCH,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_GEMM_LAUNCH if traffic is not None else None,
                          "kernel": "every matrix-core GEMM launch (gemm2_kernel + split-K reducer; precision fp32: the "
                                    "fp32-MFMA kernel) of 3 steps right after the timed steps, averaged per step (NT/NN/TN, "
                                    "implicit-GEMM convolutions, grouped weight gradients); duration = in-kernel clock, "
