@@ -53,7 +53,9 @@ def parse_args(argv=None):
                     help="base = BERT-base + ResNet-50 (BASELINE configs[1]); large = BERT-large + ResNet-101 (configs[3])")
     ap.add_argument("--mode", default="train", choices=["train", "fwd"],
                     help="train = the BASELINE metric; fwd = forward only (training-mode BatchNorm, no backward)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="bf16 (BASELINE configs[1]); fp32 = the exact mode; fp8 = configs[4]: e4m3 operands in the text encoder's "
+                         "forward Linears over bf16 storage (quote it with --batch 128)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: every step takes its batch from "
@@ -199,7 +201,7 @@ def main(argv=None):
     else:
         model = mm.MultimodalTransformerModel()  # BERT-base + ResNet-50 + fusion head, random init (no checkpoints offline)
         fwd_gflop = FWD_GFLOP_PER_PAIR * (args.seq / 128.0 if args.seq != 128 else 1.0)
-    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
+    peak = PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS  # (non-MX fp8 MFMA has the bf16 rate)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "base":
         cpu = cpu_baseline(model, 16, args.cpu_baseline_steps)

@@ -33,6 +33,7 @@ extern "C" {
 
 #define MMSA_F32 0
 #define MMSA_BF16 1
+#define MMSA_FP8 2 /* encoder cfg.dtype only: bf16 storage, fp8 (OCP e4m3) operands in the text encoder's forward Linears */
 
 /* GEMM implementation selector */
 #define MMSA_GEMM_F32_SIMT 0  /* fp32 storage: the exact-fp32 mode as the engines run it — the fp32-MFMA kernel when the problem is
@@ -100,6 +101,13 @@ int mmsa_gemm(const mmsa_gemm_desc* d, int32_t impl, void* stream);
  * issues its four dW = dY^T X products (the `.backward()` of the reference's train step, Trainer.py:79, reaches them
  * through autograd). Returns MMSA_ERR_UNSUPPORTED (3) when the problems cannot be grouped; nothing is launched then. */
 int mmsa_gemm_group(const mmsa_gemm_desc* d, int32_t n, void* stream);
+/* fp8 (OCP e4m3, the gfx950 format) path of BASELINE.json configs[4]: mmsa_fp8_quantize turns a contiguous bf16 tensor (n % 8 == 0)
+ * into e4m3 bytes with a per-tensor scale = amax / 448 (device float; amax_ws: 4 bytes of device scratch); mmsa_gemm_fp8 is the
+ * NT GEMM of mmsa_gemm on such operands (desc->A / B: e4m3 bytes, k-contiguous rows, lda / ldb in bytes; K % 128 == 0, no
+ * gather / split): C = epilogue(scale_a * scale_b * A B^T), fp32 accumulation in v_mfma_f32_16x16x32_fp8_fp8, bf16 (or fp32)
+ * output. Returns 3 (unsupported) for shapes it does not take. */
+int mmsa_fp8_quantize(const void* x_bf16, int64_t n, void* out_e4m3, float* scale, void* amax_ws, void* stream);
+int mmsa_gemm_fp8(const mmsa_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream);
 
 /* ---- LayerNorm (nn.LayerNorm: MultimodalModel.py:122,149 eps 1e-5; BERT eps 1e-12) ------------------------- */
 int mmsa_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,

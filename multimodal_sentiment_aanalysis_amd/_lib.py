@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmsa_hip.so")
 
-MMSA_F32, MMSA_BF16 = 0, 1
+MMSA_F32, MMSA_BF16, MMSA_FP8 = 0, 1, 2
 GEMM_F32_SIMT, GEMM_BF16_MFMA, GEMM_BF16_SIMT, GEMM_F32_MFMA, GEMM_F32_VALU = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 
@@ -96,6 +96,8 @@ def _declare(L):
         "mmsa_gemm_ws_bytes": (sz, [i32, i32, i32]),
         "mmsa_gemm": (ctypes.c_int, [ctypes.POINTER(GemmDesc), i32, vp]),
         "mmsa_gemm_group": (ctypes.c_int, [ctypes.POINTER(GemmDesc), i32, vp]),
+        "mmsa_fp8_quantize": (ctypes.c_int, [vp, i64, vp, vp, vp, vp]),
+        "mmsa_gemm_fp8": (ctypes.c_int, [ctypes.POINTER(GemmDesc), vp, vp, vp]),
         "mmsa_layernorm_fwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
         "mmsa_layernorm_bwd_ws_bytes": (sz, [i32]),
         "mmsa_layernorm_bwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),

@@ -58,10 +58,14 @@ static BertLayout bert_layout(const mmsa_bert_cfg& c) {
   return o;
 }
 
+// dtype 2 (MMSA_FP8, BASELINE.json configs[4]): bf16 storage everywhere, the forward's four Linears per layer take fp8 (e4m3)
+// operands (gemm_fp8.hip). sdt = the storage type every other kernel sees.
+static inline int sdt(const mmsa_bert_cfg& c) { return c.dtype == MMSA_FP8 ? MMSA_BF16 : c.dtype; }
+
 static bool bert_cfg_ok(const mmsa_bert_cfg& c) {
   return c.batch > 0 && c.seq > 0 && c.seq <= c.max_pos && c.hidden % 64 == 0 && c.heads > 0 &&
          c.hidden == c.heads * 64 && c.intermediate % 64 == 0 && c.out_dim % 64 == 0 && c.layers > 0 &&
-         c.vocab > 0 && c.type_vocab > 0 && (c.dtype == MMSA_F32 || c.dtype == MMSA_BF16);
+         c.vocab > 0 && c.type_vocab > 0 && (c.dtype == MMSA_F32 || c.dtype == MMSA_BF16 || c.dtype == MMSA_FP8);
 }
 
 struct BertLayerWs {
@@ -75,6 +79,8 @@ struct BertWs {
   void *pooled, *dfeat_t, *dpool, *dprepool;
   void *bufA, *bufB, *bufC, *bufD, *bufI, *bufQ;
   void* ones8;  // [B*S][8] bf16 ones (grouped bias gradients, engine_common.h)
+  void *q_act, *q_w;     // fp8 mode: e4m3 copies of a Linear's input ([B*S][max(H, I)]) and weight ([max N*K])
+  float* q_scales;       // fp8 mode: [0] activation scale, [1] weight scale, [2] amax scratch (as uint)
   size_t colws_bytes;
   float *splitk, *colws, *lnws, *attnws;
   size_t splitk_bytes;
@@ -84,7 +90,7 @@ struct BertWs {
 static BertWs bert_ws(const mmsa_bert_cfg& c, void* base) {
   BertWs w;
   Bump b(base);
-  const size_t es = c.dtype == MMSA_BF16 ? 2 : 4;
+  const size_t es = sdt(c) == MMSA_BF16 ? 2 : 4;
   const size_t M = (size_t)c.batch * c.seq, H = c.hidden, I = c.intermediate;
   w.e = b.take(M * H * es);
   w.x0 = b.take(M * H * es);
@@ -123,6 +129,12 @@ static BertWs bert_ws(const mmsa_bert_cfg& c, void* base) {
   w.colws = (float*)b.take(colb);
   w.colws_bytes = colb;
   w.ones8 = b.take(M * 8 * 2);
+  w.q_act = w.q_w = nullptr; w.q_scales = nullptr;
+  if (c.dtype == MMSA_FP8) {
+    w.q_act = b.take(M * (H > I ? H : I));
+    w.q_w = b.take((size_t)I * H > 3 * H * H ? (size_t)I * H : 3 * H * H);
+    w.q_scales = (float*)b.take(64);
+  }
   w.lnws = (float*)b.take(layernorm_bwd_ws_bytes((int)H));
   w.attnws = (float*)b.take(attention_bwd_ws_bytes(c.batch, c.seq, c.heads));
   w.total = b.off;
@@ -172,27 +184,38 @@ int mmsa_bert_fwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
   const BertLayout lay = bert_layout(c);
   BertWs ws = bert_ws(c, ws_base);
   hipStream_t st = (hipStream_t)stream;
-  Eng e{c.dtype, st, ws.splitk, ws.splitk_bytes, ws.colws};
+  Eng e{sdt(c), st, ws.splitk, ws.splitk_bytes, ws.colws};
   const size_t es = e.esz();
   const int M = c.batch * c.seq, H = c.hidden, I = c.intermediate, S = c.seq;
   const int aimpl = e.attn_impl();
   auto W = [&](long off) { return (const void*)at(wt, off, es); };
   auto P = [&](long off) { return w32 + off; };
 
-  RET_IF(embed_gather(c.dtype, (const long long*)ids, W(lay.word), W(lay.pos), W(lay.type), ws.e, M, S, H, c.vocab, st));
-  RET_IF(layernorm_fwd(c.dtype, ws.e, P(lay.lnw), P(lay.lnb), ws.x0, ws.mean0, ws.rstd0, M, H, c.ln_eps, st));
+  // fp8 mode: a Linear's input and weight are quantized (per-tensor scale from their own amax) right before its GEMM
+  const bool fp8 = c.dtype == MMSA_FP8;
+  auto lin = [&](const void* x, long ldx, long woff, const float* bias, void* y, long ldy, int Mr, int N, int K, int act,
+                 void* pre, const void* add, long ldadd, int pre_is_gelu_grad) -> int {
+    if (fp8) {
+      const int rc = e.linear_fwd_fp8(x, ldx, W(woff), bias, y, ldy, Mr, N, K, act, pre, add, ldadd, pre_is_gelu_grad, ws.q_act,
+                                      ws.q_w, ws.q_scales);
+      if (rc != MMSA_ERR_UNSUPPORTED) return rc;
+    }
+    return e.linear_fwd(x, ldx, W(woff), bias, y, ldy, Mr, N, K, act, pre, add, ldadd, 0, pre_is_gelu_grad);
+  };
+  RET_IF(embed_gather(sdt(c), (const long long*)ids, W(lay.word), W(lay.pos), W(lay.type), ws.e, M, S, H, c.vocab, st));
+  RET_IF(layernorm_fwd(sdt(c), ws.e, P(lay.lnw), P(lay.lnb), ws.x0, ws.mean0, ws.rstd0, M, H, c.ln_eps, st));
   const void* x = ws.x0;
   for (int l = 0; l < c.layers; ++l) {
     const BertLayerOff& f = lay.L[l];
     BertLayerWs& a = ws.L[l];
-    RET_IF(e.linear_fwd(x, H, W(f.wqkv), P(f.bqkv), a.qkv, 3 * H, M, 3 * H, H));
+    RET_IF(lin(x, H, f.wqkv, P(f.bqkv), a.qkv, 3 * H, M, 3 * H, H, MMSA_ACT_NONE, nullptr, nullptr, 0, 0));
     RET_IF(attention_fwd(aimpl, a.qkv, mask, a.ctx, c.batch, S, c.heads, 64, st));
-    RET_IF(e.linear_fwd(a.ctx, H, W(f.wo), P(f.bo), a.s1, H, M, H, H, MMSA_ACT_NONE, nullptr, x, H));
-    RET_IF(layernorm_fwd(c.dtype, a.s1, P(f.ln1w), P(f.ln1b), a.h1, a.mean1, a.rstd1, M, H, c.ln_eps, st));
+    RET_IF(lin(a.ctx, H, f.wo, P(f.bo), a.s1, H, M, H, H, MMSA_ACT_NONE, nullptr, x, H, 0));
+    RET_IF(layernorm_fwd(sdt(c), a.s1, P(f.ln1w), P(f.ln1b), a.h1, a.mean1, a.rstd1, M, H, c.ln_eps, st));
     // a.pre receives gelu'(pre-activation): the factor the backward multiplies by (one exp / erf for both outputs)
-    RET_IF(e.linear_fwd(a.h1, H, W(f.w1), P(f.b1), a.act, I, M, I, H, MMSA_ACT_GELU, a.pre, nullptr, 0, 0, gelu_factor()));
-    RET_IF(e.linear_fwd(a.act, I, W(f.w2), P(f.b2), a.s2, H, M, H, I, MMSA_ACT_NONE, nullptr, a.h1, H));
-    RET_IF(layernorm_fwd(c.dtype, a.s2, P(f.ln2w), P(f.ln2b), a.out, a.mean2, a.rstd2, M, H, c.ln_eps, st));
+    RET_IF(lin(a.h1, H, f.w1, P(f.b1), a.act, I, M, I, H, MMSA_ACT_GELU, a.pre, nullptr, 0, gelu_factor()));
+    RET_IF(lin(a.act, I, f.w2, P(f.b2), a.s2, H, M, H, I, MMSA_ACT_NONE, nullptr, a.h1, H, 0));
+    RET_IF(layernorm_fwd(sdt(c), a.s2, P(f.ln2w), P(f.ln2b), a.out, a.mean2, a.rstd2, M, H, c.ln_eps, st));
     x = a.out;
   }
   // pooler on the first token of every sequence (row stride S*H), then the projection into the fusion width (fp32 out)
@@ -221,7 +244,7 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
   const BertLayout lay = bert_layout(c);
   BertWs ws = bert_ws(c, ws_base);
   hipStream_t st = (hipStream_t)stream;
-  Eng e{c.dtype, st, ws.splitk, ws.splitk_bytes, ws.colws};
+  Eng e{sdt(c), st, ws.splitk, ws.splitk_bytes, ws.colws};
   const size_t es = e.esz();
   const int M = c.batch * c.seq, H = c.hidden, I = c.intermediate, S = c.seq, B = c.batch, D = c.out_dim;
   // Frozen parameter groups (N2: the curriculum phases of dataLoader/MultiTaskTrainer.py:50-177 and train.py:90-92 freeze
@@ -242,7 +265,7 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
     layer_frozen[l] = all_frozen(5 + 16 * l, 16);
     if (!layer_frozen[l] && emb_frozen) lowest = l;
   }
-  if (c.dtype == MMSA_BF16) {  // bias gradients ride in the grouped weight-gradient launch (Eng::wgrad_group)
+  if (sdt(c) == MMSA_BF16) {  // bias gradients ride in the grouped weight-gradient launch (Eng::wgrad_group)
     RET_IF(fill_ones_bf16(ws.ones8, (long)M * 8, st));
     e.ones8 = ws.ones8;
     e.col_ws_bytes = ws.colws_bytes;
@@ -255,14 +278,14 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
 
   const void* xL = ws.L[c.layers - 1].out;
   // projection + pooler
-  RET_IF(cast_f32(c.dtype, dfeat, ws.dfeat_t, (long)B * D, st));
+  RET_IF(cast_f32(sdt(c), dfeat, ws.dfeat_t, (long)B * D, st));
   if (!tail_frozen) {
     RET_IF(e.bias_grad(ws.dfeat_t, D, G(lay.bproj), B, D, acc));
     RET_IF(e.linear_wgrad(ws.dfeat_t, D, ws.pooled, H, G(lay.wproj), B, D, H, acc));
   }
   if (tail_frozen && lowest == nl) return MMSA_OK;  // nothing trainable in this encoder
   RET_IF(e.linear_dgrad(ws.dfeat_t, D, W(lay.wproj), ws.dpool, H, B, D, H));
-  RET_IF(tanh_bwd(c.dtype, ws.dpool, ws.pooled, ws.dprepool, (long)B * H, st));
+  RET_IF(tanh_bwd(sdt(c), ws.dpool, ws.pooled, ws.dprepool, (long)B * H, st));
   if (!tail_frozen) {
     RET_IF(e.bias_grad(ws.dprepool, H, G(lay.bp), B, H, acc));
     RET_IF(e.linear_wgrad(ws.dprepool, H, xL, (long)S * H, G(lay.wp), B, H, H, acc));
@@ -282,14 +305,14 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
     const bool last_needed = (l == lowest);  // nothing trainable below: this layer's input needs no gradient
     void* ds2 = bB;
     // ds2 is also dY of the FFN output Linear: its bias gradient (column sums of ds2) comes out of the same pass
-    RET_IF(layernorm_bwd(c.dtype, dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, G(f.ln2w), G(f.ln2b), acc, ws.lnws, M, H, st,
+    RET_IF(layernorm_bwd(sdt(c), dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, G(f.ln2w), G(f.ln2b), acc, ws.lnws, M, H, st,
                          G(f.b2)));
     void* dpre = ws.bufI;
     RET_IF(e.linear_dgrad(ds2, H, W(f.w2), dpre, I, M, H, I, a.pre, I, nullptr, 0, gelu_factor()));  // * gelu'(pre), stored by the forward
     void* dh1 = bC;
     RET_IF(e.linear_dgrad(dpre, I, W(f.w1), dh1, H, M, I, H, nullptr, 0, ds2, H));  // + residual branch
     void* ds1 = dOut;
-    RET_IF(layernorm_bwd(c.dtype, dh1, a.s1, a.mean1, a.rstd1, P(f.ln1w), ds1, G(f.ln1w), G(f.ln1b), acc, ws.lnws, M, H, st,
+    RET_IF(layernorm_bwd(sdt(c), dh1, a.s1, a.mean1, a.rstd1, P(f.ln1w), ds1, G(f.ln1w), G(f.ln1b), acc, ws.lnws, M, H, st,
                          G(f.bo)));  // + bias gradient of the attention output Linear
     void* dctx = ws.bufD;
     RET_IF(e.linear_dgrad(ds1, H, W(f.wo), dctx, H, M, H, H));
@@ -321,11 +344,11 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
   if (lowest >= 0) return MMSA_OK;  // the embeddings are frozen
   // embeddings
   void* de = bB;
-  RET_IF(layernorm_bwd(c.dtype, dOut, ws.e, ws.mean0, ws.rstd0, P(lay.lnw), de, G(lay.lnw), G(lay.lnb), acc, ws.lnws, M, H, st));
+  RET_IF(layernorm_bwd(sdt(c), dOut, ws.e, ws.mean0, ws.rstd0, P(lay.lnw), de, G(lay.lnw), G(lay.lnb), acc, ws.lnws, M, H, st));
   if (!acc && c.type_vocab > 1 &&
       hipMemsetAsync(G(lay.type) + H, 0, (size_t)(c.type_vocab - 1) * H * sizeof(float), st) != hipSuccess)
     return MMSA_ERR_LAUNCH;
-  RET_IF(embed_backward(c.dtype, (const long long*)ids, de, G(lay.word), G(lay.pos), G(lay.type), acc, ws.colws, B, S, H,
+  RET_IF(embed_backward(sdt(c), (const long long*)ids, de, G(lay.word), G(lay.pos), G(lay.type), acc, ws.colws, B, S, H,
                         c.vocab, c.max_pos, st));
   if (cb) cb(user, 0, lay.L[0].wqkv);
   return MMSA_OK;

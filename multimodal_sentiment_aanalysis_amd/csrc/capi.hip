@@ -66,6 +66,14 @@ int mmsa_gemm_group(const mmsa_gemm_desc* d, int32_t n, void* stream) {
   return gemm_bf16_launch_group(ps, cs, n, (hipStream_t)stream);
 }
 
+int mmsa_fp8_quantize(const void* x_bf16, int64_t n, void* out_e4m3, float* scale, void* amax_ws, void* stream) {
+  return fp8_quantize(x_bf16, n, out_e4m3, scale, (unsigned*)amax_ws, (hipStream_t)stream);
+}
+int mmsa_gemm_fp8(const mmsa_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream) {
+  if (!d || !d->A || !d->B || !d->C || !scale_a || !scale_b) return MMSA_ERR_ARG;
+  return gemm_fp8_launch(to_params(d), scale_a, scale_b, (hipStream_t)stream);
+}
+
 int mmsa_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                        float* rstd, int32_t M, int32_t H, float eps, void* stream) {
   if (!x || !gamma || !beta || !y || M <= 0) return MMSA_ERR_ARG;

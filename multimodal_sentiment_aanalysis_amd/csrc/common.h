@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // storage dtype tags (activations / working weights); math is always fp32 accumulate
 #define MMSA_F32 0
 #define MMSA_BF16 1
+#define MMSA_FP8 2  // bf16 storage + fp8 (e4m3) operands in the text encoder's forward Linears (BASELINE configs[4])
 
 // epilogue activations
 #define MMSA_ACT_NONE 0

@@ -1,0 +1,194 @@
+// fp8 (OCP e4m3, the CDNA4 format) GEMM for the encoder's forward Linears — BASELINE.json configs[4] "fp8 MFMA encoder GEMMs
+// (CDNA4 fp8), bf16 accumulate... " (accumulation here is fp32 in the MFMA, outputs are stored bf16).
+//
+//   C[M,N] = epilogue( sA * sB * sum_k Aq[m][k] * Bq[n][k] )      Aq, Bq: e4m3 bytes, k-contiguous rows ("NT")
+//
+// with per-tensor scales sA, sB (device floats) written by the quantizer below from the tensor's own absolute maximum
+// ("current scaling": amax pass, then x / (amax / 448) rounded to e4m3). v_mfma_f32_16x16x32_fp8_fp8 has the bf16 MFMA's
+// rate on gfx950 (only the MX-scaled K = 128 forms are faster), so what fp8 buys this kernel family is BYTES: a K step of 128
+// values is the same 128-byte LDS row as 64 bf16 values — the second-generation bf16 kernel is L2->LDS-rate bound on the
+// BERT shapes, fp8 halves that traffic per FLOP.
+//
+// Structure (first-generation shape, on purpose simple): 128x128 tile per 256-thread workgroup (4 waves, 2x2, 4x4 MFMA tiles
+// each), K step = 128 bytes, two LDS stages of 32 KiB filled by global_load_lds (16 B per lane, lane-linear 1-KiB pieces, the
+// 16-byte XOR swizzle of gemm_tile.h applied to the per-lane SOURCE address and to the fragment reads), one
+// vmcnt(0) + barrier per step. A lane's ds_read_b128 of chunk (g + 4h) feeds TWO MFMAs (bytes 0-7 and 8-15): A and B use the
+// same chunk -> k-set assignment, so every k meets its partner exactly once, in a permuted order that the sum does not see.
+// Epilogue: the shared float4 epilogue of the other GEMMs (bias, GELU with gelu' side output, residual add, bf16 / fp32 out).
+#include <stdlib.h>
+#include "gemm.h"
+#include "gemm_epilogue.h"
+#include "gemm_tile.h"
+#include "ops.h"
+
+#define Q_BM 128
+#define Q_BN 128
+#define Q_BKB 128  // bytes (= fp8 values) per K step
+#define Q_TILE 16384
+#define Q_STAGE 32768
+#define FP8_MAX 448.0f
+
+struct Fp8Params {
+  GemmParams g;           // M, N, K (in fp8 values), lda, ldb (bytes per row), C / epilogue fields as in gemm.h
+  const float* scale_a;   // device scalars
+  const float* scale_b;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Params q) {
+  const GemmParams& p = q.g;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (p.N + Q_BN - 1) / Q_BN, ntm = (p.M + Q_BM - 1) / Q_BM;
+  const int nblk = ntm * ntn;
+  int bid = blockIdx.x;
+  {  // blocks b and b + 8 share an XCD (L2): give each XCD a contiguous run of tiles (bijective for any block count)
+    const int qq = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + loc;
+  }
+  const int tm = bid / ntn, tn = bid - tm * ntn;
+  const int m0 = tm * Q_BM, n0 = tn * Q_BN;
+  stamp_begin(p.stamp);
+  const unsigned char* __restrict__ A = (const unsigned char*)p.A;
+  const unsigned char* __restrict__ B = (const unsigned char*)p.B;
+  const int nk = p.K / Q_BKB;
+
+  // staging map: wave-instruction i of wave w fills the 1-KiB piece 4 w + i = rows 8 (4w + i) .. + 7; lane -> row + (l >> 3),
+  // physical 16-byte chunk l & 7 holds logical chunk (l & 7) ^ (row & 7). Rows past the end are clamped (computed, never stored).
+  const unsigned char* srcA[4];
+  const unsigned char* srcB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ (row & 7);
+    const int ma = min(m0 + row, p.M - 1), nb = min(n0 + row, p.N - 1);
+    srcA[i] = A + (long)ma * p.lda + ch * 16;
+    srcB[i] = B + (long)nb * p.ldb + ch * 16;
+  }
+  auto issue = [&](int stage, int kt) __attribute__((always_inline)) {
+    const long koff = (long)kt * Q_BKB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned char* da = smem + stage * Q_STAGE + (wave * 4 + i) * 1024;
+      unsigned char* db = da + Q_TILE;
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)da, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)db, 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r16 = lane & 15, g = lane >> 4;
+  typedef __attribute__((ext_vector_type(2))) long i64x2;
+
+  if (nk > 0) issue(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < nk) issue(st ^ 1, kt + 1);
+    const unsigned char* ta = smem + st * Q_STAGE;
+    const unsigned char* tb = ta + Q_TILE;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      i64x2 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *(const i64x2*)(ta + kc_off(wm * 64 + i * 16 + r16, g + 4 * h));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *(const i64x2*)(tb + kc_off(wn * 64 + j * 16 + r16, g + 4 * h));
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[j][e], fa[i][e], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+  }
+  // lane holds C[m = .. + r16][n = .. + 4 g + (0..3)] (swapped operands: D rows = n, columns = m)
+  const float alpha = q.scale_a[0] * q.scale_b[0];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + r16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * g;
+      if (m < p.M && n < p.N) gemm_epilogue4<bf16>(p, m, n, acc[i][j] * alpha);
+    }
+  }
+  stamp_end(p.stamp);
+}
+
+// ---- quantizer: bf16 -> e4m3 with the tensor's own scale ------------------------------------------------------------------
+// amax_bits: the IEEE bits of max |x| (non-negative floats order like unsigned integers), zeroed by the launcher
+__global__ __launch_bounds__(256) void fp8_amax_kernel(const bf16* __restrict__ x, long n8, unsigned* __restrict__ amax_bits) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const bf16x8 v = *(const bf16x8*)(x + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[e]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));
+}
+__global__ __launch_bounds__(256) void fp8_quant_kernel(const bf16* __restrict__ x, long n8, const unsigned* __restrict__ amax_bits,
+                                                        unsigned char* __restrict__ out, float* __restrict__ scale_out) {
+  const float amax = fmaxf(__uint_as_float(*amax_bits), 1e-20f);
+  const float scale = amax * (1.0f / FP8_MAX), inv = FP8_MAX / amax;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const bf16x8 v = *(const bf16x8*)(x + i * 8);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf((float)v[e] * inv, -FP8_MAX), FP8_MAX);
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    typedef __attribute__((ext_vector_type(2))) int i32x2_;
+    *(i32x2_*)(out + i * 8) = i32x2_{lo, hi};
+  }
+}
+
+// x[n] bf16 (n % 8 == 0) -> out[n] e4m3 bytes, *scale = amax / 448; `amax_ws`: 4 bytes of device scratch
+int fp8_quantize(const void* x, long n, void* out, float* scale, unsigned* amax_ws, hipStream_t st) {
+  if (!x || !out || !scale || !amax_ws || n <= 0 || (n % 8)) return MMSA_ERR_ARG;
+  if (hipMemsetAsync(amax_ws, 0, sizeof(unsigned), st) != hipSuccess) return MMSA_ERR_LAUNCH;
+  const long n8 = n / 8;
+  const int blocks = (int)min((n8 + 255) / 256, 2048L);
+  hipLaunchKernelGGL(fp8_amax_kernel, dim3(blocks), dim3(256), 0, st, (const bf16*)x, n8, amax_ws);
+  hipLaunchKernelGGL(fp8_quant_kernel, dim3(blocks), dim3(256), 0, st, (const bf16*)x, n8, (const unsigned*)amax_ws,
+                     (unsigned char*)out, scale);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+bool gemm_fp8_eligible(const GemmParams& p) {
+  return p.gather == 0 && !p.a_kmajor && !p.b_kmajor && p.split_k <= 1 && !(p.K % Q_BKB) && !(p.N % 4) && !(p.lda % 16) &&
+         !(p.ldb % 16) && p.M > 0 && p.c_gw == 0 && !(p.out_f32 && p.accumulate);
+}
+
+// p.A / p.B: e4m3 bytes (k-contiguous rows, lda / ldb in BYTES = fp8 elements); everything else as a bf16 NT GEMM of gemm.h
+int gemm_fp8_launch(const GemmParams& pin, const float* scale_a, const float* scale_b, hipStream_t st) {
+  if (!gemm_fp8_eligible(pin) || !scale_a || !scale_b) return MMSA_ERR_UNSUPPORTED;
+  Fp8Params q;
+  q.g = pin;
+  q.scale_a = scale_a;
+  q.scale_b = scale_b;
+  const int slot = gemm_prof_open(q.g, st);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE);
+    attr = true;
+  }
+  const int blocks = cdiv(pin.M, Q_BM) * cdiv(pin.N, Q_BN);
+  hipLaunchKernelGGL(gemm_fp8_kernel, dim3(blocks), dim3(256), 2 * Q_STAGE, st, q);
+  gemm_prof_close(slot, st);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}

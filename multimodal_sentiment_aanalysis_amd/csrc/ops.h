@@ -6,6 +6,11 @@
 
 int gemm_bf16_simt_launch(const GemmParams& p, hipStream_t st);
 
+// gemm_fp8.hip
+int fp8_quantize(const void* x_bf16, long n, void* out_e4m3, float* scale, unsigned* amax_ws, hipStream_t st);
+bool gemm_fp8_eligible(const GemmParams& p);
+int gemm_fp8_launch(const GemmParams& p, const float* scale_a, const float* scale_b, hipStream_t st);
+
 // rowops.hip
 int partial_finalize(const float* part, int nblk, long stride, int n, float* out, int accumulate, float scale,
                      hipStream_t st);

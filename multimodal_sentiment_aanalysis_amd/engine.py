@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (HEAD_CLASSIFIER, HEAD_CROSS_MODAL, HEAD_MM_FUSION, HEAD_PROJECTION, HEAD_WEIGHTED, MMSA_BF16,
-                   MMSA_F32, RANGE_CB, BertCfg, HeadCfg, MmsaError, ResnetCfg, check, param_table, ptr, ptr_array,
+                   MMSA_F32, MMSA_FP8, RANGE_CB, BertCfg, HeadCfg, MmsaError, ResnetCfg, check, param_table, ptr, ptr_array,
                    stream_ptr)
 
 BERT_BASE = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, max_pos=512, type_vocab=2,
@@ -61,7 +61,9 @@ def _require_gpu(t, what):
 class EngineModule(nn.Module):
     """Base: flat parameter table + (re)binding into shared flat buffers."""
 
-    precision = "bf16"  # storage type of encoder activations / working weights ("bf16" | "fp32"); heads are fp32
+    # storage type of encoder activations / working weights: "bf16" | "fp32" (heads are always fp32), or "fp8" = bf16 storage with
+    # fp8 (e4m3) operands in the text encoder's forward Linears (BASELINE.json configs[4]; the image encoder then runs as bf16)
+    precision = "bf16"
 
     def _setup_tables(self, specs, bspecs, numel, bn_numel):
         self._specs, self._bspecs, self._numel, self._bn_numel = specs, bspecs, int(numel), int(bn_numel)
@@ -205,11 +207,11 @@ class EngineModule(nn.Module):
 
     # ---- working copy in the storage dtype ------------------------------------------------------------------------
     def _storage_code(self):
-        return MMSA_BF16 if self.precision == "bf16" else MMSA_F32
+        return MMSA_BF16 if self.precision in ("bf16", "fp8") else MMSA_F32
 
     def _sync_wt(self):
         """Refresh the bf16 working copy when the fp32 master changed (torch optimizer step, load_state_dict)."""
-        if self.precision != "bf16":
+        if self.precision not in ("bf16", "fp8"):
             return self._flat_w
         token = self._version_token()
         if token != self._wt_token:
@@ -292,7 +294,7 @@ def materialize(root, device, precision=None):
     nbt_total = sum(len(e._nbt) for e in engs)
     flat_w = torch.zeros(total, dtype=torch.float32, device=device)
     flat_g = torch.zeros(total, dtype=torch.float32, device=device)
-    need_bf16 = any(e.precision == "bf16" for e in engs)
+    need_bf16 = any(e.precision in ("bf16", "fp8") for e in engs)
     flat_wt = torch.zeros(total, dtype=torch.bfloat16, device=device) if need_bf16 else None
     flat_bn = torch.zeros(max(bn_total, 1), dtype=torch.float32, device=device)
     flat_nbt = torch.zeros(max(nbt_total, 1), dtype=torch.long, device=device)
@@ -333,7 +335,7 @@ class _BertFn(torch.autograd.Function):
     def forward(ctx, eng, dummy, ids, mask):
         L = _lib.load()
         B, S = ids.shape
-        cfg = _bert_cfg(eng.config, B, S, eng.out_dim, eng._storage_code())
+        cfg = _bert_cfg(eng.config, B, S, eng.out_dim, MMSA_FP8 if eng.precision == "fp8" else eng._storage_code())
         nbytes = L.mmsa_bert_ws_bytes(ctypes.byref(cfg))
         if nbytes == 0:
             raise MmsaError(f"unsupported BERT configuration {eng.config} B={B} S={S}")

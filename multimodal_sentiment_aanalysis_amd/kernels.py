@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, GEMM_BF16_MFMA, GEMM_BF16_SIMT,
-                   GEMM_F32_SIMT, ConvGeom, GemmDesc, check, dtype_code, ptr, stream_ptr)
+                   GEMM_F32_SIMT, ConvGeom, GemmDesc, check, dtype_code, ptr, stream_ptr)  # noqa: F401
 
 _ws_cache = {}
 
@@ -64,6 +64,36 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, gather=0, geom
         impl = default_impl(A)
     check(L.mmsa_gemm(ctypes.byref(d), impl, stream_ptr()), "mmsa_gemm")
     return C
+
+
+def fp8_quantize(x):
+    """x: contiguous bf16 tensor (numel % 8 == 0) -> (e4m3 bytes as uint8, same shape; scale: 1-element fp32 tensor = amax / 448)."""
+    L = _lib.load()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    amax = torch.empty(1, dtype=torch.int32, device=x.device)
+    check(L.mmsa_fp8_quantize(ptr(x), x.numel(), ptr(out), ptr(scale), ptr(amax), stream_ptr()), "mmsa_fp8_quantize")
+    return out, scale
+
+
+def gemm_fp8(Aq, sa, Bq, sb, C, bias=None, act=ACT_NONE, add=None, C2=None):
+    """C[M,N] = epilogue(sa * sb * Aq[M,K] Bq[N,K]^T) on e4m3 bytes (mmsa_gemm_fp8). Returns the status (3 = unsupported shape)."""
+    L = _lib.load()
+    M, Kd = Aq.shape
+    N = Bq.shape[0]
+    d = GemmDesc()
+    d.A, d.B, d.C = Aq.data_ptr(), Bq.data_ptr(), C.data_ptr()
+    d.M, d.N, d.K = M, N, Kd
+    d.lda, d.ldb, d.ldc = Kd, Kd, N
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.act = act
+    d.add = add.data_ptr() if add is not None else None
+    d.ldadd = N
+    d.C2 = C2.data_ptr() if C2 is not None else None
+    d.ldc2 = N
+    d.out_f32 = int(C.dtype == torch.float32)
+    d.split_k = 1
+    return L.mmsa_gemm_fp8(ctypes.byref(d), ptr(sa), ptr(sb), stream_ptr())
 
 
 def gemm_group(jobs):

@@ -776,3 +776,38 @@ def test_frozen_groups_skip_kernels_and_keep_gradients(dev, which):
             assert g_fr[k] is None, k
         else:
             assert g_fr[k] is not None and torch.equal(g_fr[k], g), f"{which}: gradient of trainable {k} changed"
+
+
+
+def test_bert_engine_fp8(dev):
+    """BASELINE.json configs[4] at the engine level: the text encoder with fp8 (e4m3) operands in its forward Linears (precision
+    "fp8": bf16 storage, per-tensor current scaling, bf16 backward) against the same encoder in bf16. e4m3 keeps 3 mantissa bits:
+    every fp8 GEMM adds ~4-6 % (rms) to its output, so the bound is loose by construction — what it pins is that the fp8 path is
+    wired correctly end to end (scales, epilogues, side outputs feeding the backward) and trains."""
+    torch.manual_seed(0)
+    cfg = dict(MINI_BERT, hidden=256, heads=4, intermediate=1024)  # K = 256 / 1024: multiples of the fp8 K step (128)
+    _, ids, mask, _ = synth_batch(8, 32, 32, 32, cfg["vocab"], seed=5)
+    wgt = torch.randn(8, 256, generator=torch.Generator().manual_seed(9)).to(dev)
+    outs, grads = {}, {}
+    L = _lib.load()
+    for prec in ("bf16", "fp8"):
+        torch.manual_seed(0)
+        net = BertTextNet(cfg)
+        net.precision = prec
+        net.to(dev)
+        L.mmsa_prof_mode(0)
+        L.mmsa_prof_begin(1024)
+        out = net(ids.to(dev), mask.to(dev))
+        torch.cuda.synchronize()
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        L.mmsa_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+        (out * wgt).sum().backward()
+        outs[prec], grads[prec] = out.detach().float().cpu(), _grads(net)
+        assert torch.isfinite(outs[prec]).all()
+    rel = ((outs["fp8"] - outs["bf16"]).norm() / outs["bf16"].norm()).item()
+    print(f"fp8 vs bf16 text feature: relative L2 {rel:.3e}")
+    assert 1e-4 < rel < 0.25, rel  # > 0: the fp8 kernels really ran; < 0.25: they compute the same function
+    worst = max(((grads["fp8"][k].double() - g.double()).norm() / max(g.double().norm(), 1e-9)).item() for k, g in grads["bf16"].items()
+                if g.double().norm() > 1e-6)
+    print(f"fp8 vs bf16 gradients: worst relative L2 {worst:.3e}")
+    assert worst < 0.6, worst

@@ -153,6 +153,42 @@ def test_gemm_f32_mfma_matches_valu_bitwise(dev, case):
     assert torch.equal(C1, C2), f"{case}: max |diff| {(C1 - C2).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("M,N,Kd", [(256, 256, 128), (1024, 768, 768), (300, 136, 256), (8192, 3072, 768), (77, 260, 384)])
+def test_gemm_fp8(dev, M, N, Kd):
+    """BASELINE.json configs[4]: the fp8 (OCP e4m3) quantizer and NT GEMM (gemm_fp8.hip). (1) the quantizer's bytes are torch's
+    own float8_e4m3fn rounding of x / scale with scale = amax / 448; (2) the GEMM equals the float64 product of the DEQUANTIZED
+    operands (what the MFMA multiplies is exactly those values; fp32 accumulation, one bf16 output rounding) — this also pins
+    the operand lane maps of v_mfma_f32_16x16x32_fp8_fp8 and the k-permuted fragment reads; (3) bias + GELU + residual epilogue."""
+    A = rnd((M, Kd), torch.bfloat16, dev, 1)
+    B = rnd((N, Kd), torch.bfloat16, dev, 2, 0.05)
+    Aq, sa = K.fp8_quantize(A)
+    Bq, sb = K.fp8_quantize(B)
+    for x, q, s_ in ((A, Aq, sa), (B, Bq, sb)):
+        amax = x.float().abs().max()
+        assert abs(s_.item() - amax.item() / 448.0) <= 1e-6 * amax.item()
+        want = (x.float() / s_).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+        frac = (want != q).float().mean().item()
+        assert frac < 1e-3, f"quantizer differs from torch's e4m3 rounding on {frac:.2%} of the elements"
+    Ad = Aq.view(torch.float8_e4m3fn).float().cpu().double() * sa.item()
+    Bd = Bq.view(torch.float8_e4m3fn).float().cpu().double() * sb.item()
+    ref = Ad @ Bd.T
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    assert K.gemm_fp8(Aq, sa, Bq, sb, C) == 0
+    assert_close(C, ref, torch.bfloat16, "fp8 NT")
+    # the fp8 result vs the bf16 operands' exact product: e4m3 keeps 3 mantissa bits (about 4-6 % of the output's rms)
+    exact = A.cpu().double() @ B.cpu().double().T
+    rel = ((C.cpu().double() - exact).norm() / exact.norm()).item()
+    assert rel < 0.08, rel
+    bias = rnd((N,), torch.float32, dev, 3)
+    add = rnd((M, N), torch.bfloat16, dev, 4)
+    assert K.gemm_fp8(Aq, sa, Bq, sb, C, bias=bias, act=ACT_GELU, add=add) == 0
+    assert_close(C, F.gelu(ref + bias.cpu().double()) + add.cpu().double(), torch.bfloat16, "fp8 bias+gelu+residual")
+    Cf = torch.empty(M, N, dtype=torch.float32, device=dev)
+    assert K.gemm_fp8(Aq, sa, Bq, sb, Cf) == 0
+    assert_close(Cf, ref, torch.float32 if False else torch.bfloat16, "fp8 NT fp32 out")
+    assert ((Cf.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-5, "fp32 output: accumulation order only"
+
+
 CONVS = [  # B, H, W, Cin, Cout, k, stride, pad
     (2, 8, 8, 64, 64, 3, 1, 1),
     (2, 9, 7, 64, 128, 3, 2, 1),
