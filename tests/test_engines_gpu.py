@@ -807,7 +807,6 @@ def test_bert_engine_fp8(dev):
     rel = ((outs["fp8"] - outs["bf16"]).norm() / outs["bf16"].norm()).item()
     print(f"fp8 vs bf16 text feature: relative L2 {rel:.3e}")
     assert 1e-4 < rel < 0.25, rel  # > 0: the fp8 kernels really ran; < 0.25: they compute the same function
-    worst = max(((grads["fp8"][k].double() - g.double()).norm() / max(g.double().norm(), 1e-9)).item() for k, g in grads["bf16"].items()
-                if g.double().norm() > 1e-6)
-    print(f"fp8 vs bf16 gradients: worst relative L2 {worst:.3e}")
-    assert worst < 0.6, worst
+    # gradients: the backward is the bf16 one, evaluated at the fp8 forward's (1 % different) activations; per tensor, relative
+    # to its own norm with the usual floor for analytically-zero gradients (the key bias under softmax)
+    _check_grads(grads["fp8"], grads["bf16"], 0.25, "fp8 forward / bf16 backward vs bf16", l2=True)
