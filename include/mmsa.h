@@ -258,13 +258,15 @@ int mmsa_adamw_step(float* w, const float* g, float* m, float* v, void* w16, int
  * on the device, without a host sync. mmsa_grad_norm (both forms) writes norm_out[1] = -1 when the gradient norm -- or, in
  * the guarded form, the device scalar *loss (may be NULL) -- is not finite; mmsa_adamw_step (both forms) returns without
  * touching w, m, v, w16 when norm_clip[1] < 0. *step_count (device int32, may be NULL in the guard) counts the APPLIED steps:
- * the guard increments it when the step is not skipped, mmsa_adamw_step_dev takes its bias correction from it. */
+ * the guard increments it when the step is not skipped and — norm_out then has FOUR floats — writes the AdamW bias corrections
+ * of that count, 1 - beta1^t and sqrt(1 - beta2^t), to norm_out[2], norm_out[3]; mmsa_adamw_step_dev reads them from norm_clip. */
 int mmsa_grad_norm_guard(const float* g, int64_t n, float grad_scale, float max_norm, const float* loss, int32_t* step_count,
-                         float* norm_out, void* ws, void* stream);
+                         float* norm_out /*[4]*/, void* ws, float beta1, float beta2, void* stream);
 /* the norm over `nranges` disjoint ranges (host arrays of element offsets / lengths, nranges <= 256) of one gradient buffer:
  * the trainable sub-ranges of a curriculum phase (dataLoader/MultiTaskTrainer.py:50-177 freezes everything else) */
 int mmsa_grad_norm_ranges(const float* g, const int64_t* offsets, const int64_t* lengths, int32_t nranges, float grad_scale,
-                          float max_norm, const float* loss, int32_t* step_count, float* norm_out, void* ws, void* stream);
+                          float max_norm, const float* loss, int32_t* step_count, float* norm_out /*[4]*/, void* ws,
+                          float beta1, float beta2, void* stream);
 /* g[0, n) *= norm_clip[1] (no-op on a skipped step): the in-place scaling clip_grad_norm_ applies to gradients that no
  * optimizer owns (phase 3 of dataLoader/MultiTaskTrainer.py:147-177 clips four modules and steps one) */
 int mmsa_grad_scale_clip(float* g, int64_t n, const float* norm_clip, void* stream);

@@ -330,11 +330,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
-// Minimum rows a lane walks in the partial-sum kernels. 16 left the mid-size layers with 49-392 workgroups for 256 CUs
-// (C = 64 at 200704 rows: 392; C = 256 at 12544 rows: 98): 4 gives every layer >= 4x as many chunks (up to the 1024 cap).
+// Minimum rows a lane walks in the partial-sum kernels. 16 leaves the mid-size layers with 49-392 workgroups for 256 CUs
+// (C = 64 at 200704 rows: 392; C = 256 at 12544 rows: 98), yet 4 (4x the chunks) measured SLOWER on the whole step (19.66 vs
+// 19.46 ms): every extra chunk is another partial row for the finalize kernels, 114 latency-bound launches per step.
 // MMSA_BN_RPL overrides (A/B hook).
 static int bn_rows_per_lane() {
-  static const int v = [] { const char* e = getenv("MMSA_BN_RPL"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 4; }();
+  static const int v = [] { const char* e = getenv("MMSA_BN_RPL"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 16; }();
   return v;
 }
 

@@ -117,16 +117,17 @@ int mmsa_adamw_step(float* w, const float* g, float* m, float* v, void* w16, int
   return adamw_step(w, g, m, v, w16, n, lr, beta1, beta2, eps, weight_decay, step, norm_clip, grad_scale, (hipStream_t)stream);
 }
 int mmsa_grad_norm_guard(const float* g, int64_t n, float grad_scale, float max_norm, const float* loss, int32_t* step_count,
-                         float* norm_out, void* ws, void* stream) {
+                         float* norm_out, void* ws, float beta1, float beta2, void* stream) {
   if (!g || !norm_out || !ws || n <= 0) return MMSA_ERR_ARG;
-  return grad_norm(g, n, grad_scale, max_norm, norm_out, ws, (hipStream_t)stream, loss, step_count);
+  return grad_norm(g, n, grad_scale, max_norm, norm_out, ws, (hipStream_t)stream, loss, step_count, beta1, beta2);
 }
 int mmsa_grad_norm_ranges(const float* g, const int64_t* offsets, const int64_t* lengths, int32_t nranges, float grad_scale,
-                          float max_norm, const float* loss, int32_t* step_count, float* norm_out, void* ws, void* stream) {
+                          float max_norm, const float* loss, int32_t* step_count, float* norm_out, void* ws, float beta1,
+                          float beta2, void* stream) {
   if (!g || !offsets || !lengths || !norm_out || !ws) return MMSA_ERR_ARG;
   static_assert(sizeof(long) == sizeof(int64_t), "LP64");
   return grad_norm_ranges(g, (const long*)offsets, (const long*)lengths, nranges, grad_scale, max_norm, norm_out, ws,
-                          (hipStream_t)stream, loss, step_count);
+                          (hipStream_t)stream, loss, step_count, beta1, beta2);
 }
 int mmsa_grad_scale_clip(float* g, int64_t n, const float* norm_clip, void* stream) {
   if (!g || !norm_clip) return MMSA_ERR_ARG;

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void grad_sumsq_partial_kernel(const float* __
 // a skipped batch, and the host never learns which ones were skipped (no sync).
 __global__ __launch_bounds__(256) void grad_norm_finalize_kernel(const double* __restrict__ part, int nblk, float grad_scale,
                                                                  float max_norm, const float* __restrict__ loss,
-                                                                 int* __restrict__ step_count, float* __restrict__ norm_out) {
+                                                                 int* __restrict__ step_count, float* __restrict__ norm_out,
+                                                                 float b1, float b2) {
   // one block, fixed summation tree (a single thread walking the 1024 partials took 57 us)
   __shared__ double red[256];
   double s = 0.0;
@@ -45,7 +46,14 @@ __global__ __launch_bounds__(256) void grad_norm_finalize_kernel(const double* _
   norm_out[0] = norm;
   const bool ok = isfinite(norm) && (!loss || isfinite(*loss));
   norm_out[1] = !ok ? -1.f : (max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f);
-  if (step_count && ok) *step_count += 1;
+  if (step_count) {
+    // the AdamW bias corrections of the step this norm belongs to, computed ONCE here (norm_out[2], [3]): as two powf per
+    // thread of the 1 M-thread AdamW kernel they cost 0.2 ms per step (adamw_kernel 630 -> 846 us)
+    const int t = *step_count + (ok ? 1 : 0);
+    if (ok) *step_count = t;
+    norm_out[2] = 1.f - powf(b1, (float)max(t, 1));
+    norm_out[3] = sqrtf(1.f - powf(b2, (float)max(t, 1)));
+  }
 }
 
 size_t grad_norm_ws_bytes() { return 2 * SUMSQ_BLOCKS * sizeof(double); }
@@ -53,7 +61,7 @@ size_t grad_norm_ws_bytes() { return 2 * SUMSQ_BLOCKS * sizeof(double); }
 // the same norm over several disjoint ranges of one gradient buffer (the trainable sub-ranges of a curriculum phase,
 // dataLoader/MultiTaskTrainer.py:50-177): each range gets a share of the partial blocks, one finalize over all of them
 int grad_norm_ranges(const float* g, const long* offs, const long* lens, int nr, float grad_scale, float max_norm,
-                     float* norm_out, void* ws, hipStream_t st, const float* loss, int* step_count) {
+                     float* norm_out, void* ws, hipStream_t st, const float* loss, int* step_count, float b1, float b2) {
   if (nr < 1 || nr > 256) return MMSA_ERR_ARG;
   long total = 0;
   for (int r = 0; r < nr; ++r) {
@@ -71,17 +79,17 @@ int grad_norm_ranges(const float* g, const long* offs, const long* lens, int nr,
     used += (int)want;
   }
   hipLaunchKernelGGL(grad_norm_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, used, grad_scale, max_norm,
-                     loss, step_count, norm_out);
+                     loss, step_count, norm_out, b1, b2);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
 
 int grad_norm(const float* g, long n, float grad_scale, float max_norm, float* norm_out, void* ws, hipStream_t st,
-              const float* loss, int* step_count) {
+              const float* loss, int* step_count, float b1, float b2) {
   const int blocks = (int)min((n / 4 + 255) / 256 + 1, (long)SUMSQ_BLOCKS);
   hipLaunchKernelGGL(grad_sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, g, n, (double*)ws);
   hipLaunchKernelGGL(grad_norm_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, blocks, grad_scale, max_norm,
-                     loss, step_count, norm_out);
+                     loss, step_count, norm_out, b1, b2);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
@@ -111,10 +119,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
                                                     const int* __restrict__ step_count) {
   const float clip = norm_clip ? norm_clip[1] : 1.f;
   if (clip < 0.f) return;  // non-finite gradient norm / loss: the step is skipped, w, m, v and the bf16 copy stay as they are
-  if (step_count) {        // bias correction from the device-side count of applied steps (this one included)
-    const float t = (float)*step_count;
-    bc1 = 1.f - powf(b1, t);
-    bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  if (step_count) {        // bias corrections of the device-side count of applied steps: written by the norm's finalize kernel
+    bc1 = norm_clip[2];
+    bc2_sqrt = norm_clip[3];
   }
   const float coef = clip * grad_scale;
   const long n4 = n / 4;

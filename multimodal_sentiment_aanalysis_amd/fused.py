@@ -126,7 +126,8 @@ class FlatAdamW:
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.steps = torch.zeros(1, dtype=torch.int32, device=dev)  # applied (not skipped) steps
         self.norm_ws = torch.empty(_lib.load().mmsa_grad_norm_ws_bytes(), dtype=torch.uint8, device=dev)
-        self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)  # [total norm, clip coefficient | -1 = skipped]
+        # [total norm, clip coefficient | -1 = skipped, 1 - beta1^t, sqrt(1 - beta2^t)] (t = applied steps, this one included)
+        self.norm_out = torch.zeros(4, dtype=torch.float32, device=dev)
         self._offs = (ctypes.c_int64 * len(self.norm_ranges))(*[a for a, _ in self.norm_ranges])
         self._lens = (ctypes.c_int64 * len(self.norm_ranges))(*[n_ for _, n_ in self.norm_ranges])
 
@@ -139,7 +140,8 @@ class FlatAdamW:
         L = _lib.load()
         st = self.state
         check(L.mmsa_grad_norm_ranges(ptr(st.flat_g), self._offs, self._lens, len(self.norm_ranges), grad_scale, self.max_norm,
-                                      ptr(loss), ptr(self.steps), ptr(self.norm_out), ptr(self.norm_ws), stream_ptr()),
+                                      ptr(loss), ptr(self.steps), ptr(self.norm_out), ptr(self.norm_ws), self.betas[0],
+                                      self.betas[1], stream_ptr()),
               "mmsa_grad_norm_ranges")
         for a, n in self.ranges:
             w16 = None if st.flat_wt is None else st.flat_wt[a:a + n]
