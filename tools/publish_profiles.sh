@@ -1,15 +1,19 @@
 #!/bin/bash
-# usage: tools/publish_profiles.sh <prefix in gpurun_out, e.g. f2>   — copies a measurement set into profiles/ and refreshes DESIGN.md
+# usage: tools/publish_profiles.sh <prefix in gpurun_out, e.g. r2z> [round tag, default r02]  — copies a measurement set into profiles/
 set -e
 P=$1
-cp gpurun_out/pmc_traffic.json profiles/r01_pmc_traffic.json
-cp gpurun_out/${P}_shapes.csv profiles/r01_gemm_shapes.csv
+R=${2:-r02}
+C=$(git rev-parse --short HEAD)
 python3 - <<PY
 import json
+t=json.load(open('gpurun_out/pmc_traffic.json'))
+t['commit']='$C'
+json.dump(t, open('profiles/${R}_pmc_traffic.json','w'), indent=1)
 b=json.loads(open('gpurun_out/${P}_bench.json').read().strip().splitlines()[-1])
-t=json.load(open('profiles/r01_pmc_traffic.json'))['all_gemm']['hbm_bytes_per_launch']
-b['roofline']['traffic']=t
-open('profiles/r01_bench_default.json','w').write(json.dumps(b)+"\n")
+b['roofline']['traffic']=t['all_gemm']['hbm_bytes_per_launch']
+b['roofline']['traffic_source']='profiles/${R}_pmc_traffic.json (offline rocprofv3 --pmc passes, commit $C)'
+open('profiles/${R}_bench_default.json','w').write(json.dumps(b)+"\n")
 PY
-(echo "# Round 1 — rocprofv3 --kernel-trace --stats of \`python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline\` (MMSA_BENCH_NOPROF=1: no event / stamp passes)"; echo; echo "MI355X (gfx950), bf16, B=64, S=128, 224x224; 13 steps in the trace (3 warm-up + 10 timed). Commit at capture: end of round 1. Summarised from the rocpd database by tools/prof_summary.py."; echo; python3 tools/prof_summary.py gpurun_out/${P}_prof/run_results.db 13) > profiles/r01_rocprofv3_kernel_stats.md
-python3 tools/fill_design.py profiles/r01_bench_default.json profiles/r01_pmc_traffic.json tools/DESIGN.template.md
+cp gpurun_out/${P}_shapes.csv profiles/${R}_gemm_shapes.csv
+(echo "# ${R} — rocprofv3 --kernel-trace --stats of \`python3 bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline\` (MMSA_BENCH_NOPROF=1: no event / stamp / forward passes)"; echo; echo "MI355X (gfx950), bf16, B=64, S=128, 224x224; 13 steps in the trace (3 warm-up + 10 timed). Commit at capture: $C. Summarised from the rocpd database by tools/prof_summary.py."; echo; python3 tools/prof_summary.py gpurun_out/${P}_prof/run_results.db 13) > profiles/${R}_rocprofv3_kernel_stats.md
+echo "published ${R} from ${P} at $C"
