@@ -76,7 +76,15 @@ struct Eng {
     return v && atoi(v) != 0;
   }
   int gemm(const GemmParams& pin) const {
-    if (dtype != MMSA_BF16) return gemm_f32_launch(pin, st);
+    if (dtype != MMSA_BF16) {
+      GemmParams p = pin;
+      if (splitk_ws && !(p.N % 4) && gemm_f32_mfma_eligible(p)) {  // the fp32-MFMA kernel plans its own K split
+        if (p.split_k < 1) p.split_k = 1;
+        p.ws = splitk_ws;
+        p.ws_bytes = (long)splitk_bytes;
+      }
+      return gemm_f32_launch(p, st);
+    }
     if (force_simt()) return gemm_bf16_simt_launch(pin, st);
     // Few-tile, deep-K launches (stage-3/4 convolutions: 100-200 tiles of 128x128 for 256 CUs x 2 slots) get a split
     // over K so that the machine is filled; the slab reducer applies the epilogue.

@@ -304,6 +304,22 @@ int gemm_f32_mfma_launch(const GemmParams& pin, hipStream_t st) {
   GemmParams p = pin;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MMSA_ERR_ARG;
   if (p.split_k < 1) p.split_k = 1;
+  // Own K split when the caller lent a slab workspace (ws_bytes > 0): the engines size their request for the VALU kernel's
+  // 64x64 tiles; with 128x128 tiles a BERT weight gradient (768 x 3072, K = 8192) is 144 workgroups for 256 CUs x 2 slots
+  // and every forward / data gradient with N = 768 is 384. Aim at >= 2 workgroups per CU, slabs of >= 256 K values each.
+  if (p.ws && p.ws_bytes > 0 && !(p.N % 4)) {
+    const long tiles = (long)cdiv(p.M, FBM) * cdiv(p.N, FBN);
+    int split = 1;
+    if (tiles < 512) {
+      split = (int)((512 + tiles - 1) / tiles);
+      const int maxs = p.K / 256;
+      if (split > maxs) split = maxs;
+      if (split > 32) split = 32;
+      while (split > 1 && (long)split * p.M * p.N * (long)sizeof(float) > p.ws_bytes) --split;
+      if (split < 1) split = 1;
+    }
+    p.split_k = split;
+  }
   const F32Plan pl = f32_plan(p);
   dim3 grid(cdiv(p.M, FBM) * cdiv(p.N, FBN), p.split_k, 1);
   switch (pl.amode) {
