@@ -810,3 +810,33 @@ def test_bert_engine_fp8(dev):
     # gradients: the backward is the bf16 one, evaluated at the fp8 forward's (1 % different) activations; per tensor, relative
     # to its own norm with the usual floor for analytically-zero gradients (the key bias under softmax)
     _check_grads(grads["fp8"], grads["bf16"], 0.25, "fp8 forward / bf16 backward vs bf16", l2=True)
+
+
+
+def test_bert_base_full_size_backward_bf16(dev):
+    """E1 at its real size on the benchmarked kernels: BERT-base (12 layers, H = 768, 12 heads, FFN 3072), S = 128, B = 4, bf16
+    MFMA GEMMs / attention / grouped weight gradients, forward AND backward against the oracle under the bf16 storage policy
+    with gradients rounded where the device stores them (BF16G). BERT has no ReLU / BatchNorm, so — unlike the ResNet — a
+    free-running comparison is meaningful (round 1 had no full-size backward check of the text encoder)."""
+    from multimodal_sentiment_aanalysis_amd.engine import BERT_BASE
+    torch.manual_seed(0)
+    net = BertTextNet(BERT_BASE)
+    net.precision = "bf16"
+    sd = cpu_state(net)
+    B, S = 4, 128
+    _, ids, mask, _ = synth_batch(B, S, 32, 32, BERT_BASE["vocab"], seed=5)
+    mask[:, S - 9:] = 0
+    wgt = torch.randn(B, 256, generator=torch.Generator().manual_seed(9))
+
+    def feat_fn(work):
+        _, pooled = bert_forward(work, "bert.", ids, mask, BERT_BASE, BF16G)
+        return pooled @ BF16G.qw(work["proj.weight"]).t() + work["proj.bias"]
+
+    ref = feat_fn(sd)
+    net.to(dev)
+    out = net(ids.to(dev), mask.to(dev))
+    assert rel_err(out, ref) < 2e-2, f"BERT-base feature {rel_err(out, ref)}"
+    (out * wgt.to(dev)).sum().backward()
+    names = [n for n, _ in net.named_parameters()]
+    ref_g = _oracle_grads(sd, names, lambda w: (feat_fn(w) * wgt).sum())
+    _check_grads(_grads(net), ref_g, 8e-2, "BERT-base bf16 (full size)", l2=True)
