@@ -275,6 +275,8 @@ int mmsa_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w16,
                         void* stream);
 /* storage cast fp32 -> dtype (refresh of the working weights after a foreign optimizer touched the fp32 master) */
 int mmsa_cast_f32(int32_t dtype, const float* src, void* dst, int64_t n, void* stream);
+/* bf16 -> fp32 (the data-parallel step's bf16 gradient payload, widened back into the fp32 gradient buffer after the all-reduce) */
+int mmsa_widen_bf16(const void* src_bf16, float* dst, int64_t n, void* stream);
 
 /* ---- BatchNorm over the rows of [M][C] (nn.BatchNorm1d: MultimodalModel.py:181,186,194,380; BatchNorm2d of the
  * ResNet encoder on NHWC), fused affine (+ residual) + activation; two-stage deterministic statistics ----------- */

@@ -145,6 +145,11 @@ int mmsa_cast_f32(int32_t dtype, const float* src, void* dst, int64_t n, void* s
   return cast_f32(dtype, src, dst, n, (hipStream_t)stream);
 }
 
+int mmsa_widen_bf16(const void* src, float* dst, int64_t n, void* stream) {
+  if (!src || !dst) return MMSA_ERR_ARG;
+  return widen_bf16(src, dst, n, (hipStream_t)stream);
+}
+
 int mmsa_prof_begin(int32_t max_records) { return gemm_prof_begin(max_records); }
 int mmsa_prof_sample(int32_t stride, int32_t phase) { return gemm_prof_sample(stride, phase); }
 int mmsa_prof_mode(int32_t mode) { return gemm_prof_mode(mode); }

@@ -65,6 +65,7 @@ int maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, void* dx, i
 int avgpool_fwd(int dtype, const void* x, void* y, int B, int HW, int C, hipStream_t st);
 int avgpool_bwd(int dtype, const void* dy, void* dx, int B, int HW, int C, hipStream_t st);
 int cast_f32(int dtype, const float* src, void* dst, long n, hipStream_t st);
+int widen_bf16(const void* src_bf16, float* dst, long n, hipStream_t st);
 int pad_rows(int dtype, const float* src, void* dst, int rows, int cols_src, int cols_dst, hipStream_t st);
 int unpad_rows(const float* src, float* dst, int rows, int cols_src, int cols_dst, int accumulate, hipStream_t st);
 

@@ -313,6 +313,24 @@ int cast_f32(int dtype, const float* src, void* dst, long n, hipStream_t st) {
   return MMSA_OK;
 }
 
+// dst fp32 <- src bf16 (the reduced gradient payload of a data-parallel step coming back from the all-reduce, fused.py)
+__global__ __launch_bounds__(256) void widen_bf16_kernel(const bf16* __restrict__ src, float* __restrict__ dst, long n) {
+  const long n8 = n / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const bf16x8 v = *(const bf16x8*)(src + i * 8);
+    *(f32x4*)(dst + i * 8) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    *(f32x4*)(dst + i * 8 + 4) = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = (float)src[n8 * 8 + threadIdx.x];
+}
+int widen_bf16(const void* src, float* dst, long n, hipStream_t st) {
+  if (n <= 0) return MMSA_OK;
+  const int grid = (int)min((n / 8 + 255) / 256 + 1, 4096L);
+  hipLaunchKernelGGL(widen_bf16_kernel, dim3(grid), dim3(256), 0, st, (const bf16*)src, dst, n);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
 // dst[r][0:cols_dst] = src[r][0:cols_src] zero-padded (stem weight [64][147] -> [64][Kpad]) in storage type T
 template <typename T>
 __global__ void pad_rows_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols_src, int cols_dst) {

@@ -29,8 +29,13 @@ class GradReducer:
     ones. `finish()` joins the side stream before the clip. Works on CPU tensors with the gloo backend too (used by the
     world_size-2 CPU tests), where the collectives run inline."""
 
-    def __init__(self, flat_g, bucket_bytes=64 << 20, group=None, min_bucket_bytes=16 << 20):
+    def __init__(self, flat_g, bucket_bytes=64 << 20, group=None, min_bucket_bytes=16 << 20, payload="fp32"):
+        """payload "bf16" (GPU only): a range is cast to a bf16 staging buffer on the side stream, all-reduced as bf16 (half the
+        bytes on xGMI, half of RCCL's active time beside the backward) and widened back into the fp32 gradient buffer; the sum
+        over ranks then carries bf16 rounding (2^-9 relative per addition), as DDP's bf16 compression hook does."""
         self.flat_g, self.group = flat_g, group
+        self.payload = payload if flat_g.is_cuda else "fp32"
+        self._stage = None
         self.bucket_elems = max(1, bucket_bytes // flat_g.element_size())
         self.min_elems = max(1, min_bucket_bytes // flat_g.element_size())
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -82,14 +87,29 @@ class GradReducer:
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
                 for a, b in self.buckets(start, length):
-                    self.works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group,
-                                                      async_op=True))
+                    if self.payload == "bf16":
+                        self._reduce_bf16(a, b)
+                    else:
+                        self.works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                                          async_op=True))
                     self.issued.append((a, b - a))
         else:
             for a, b in self.buckets(start, length):
                 self.works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group,
                                                   async_op=True))
                 self.issued.append((a, b - a))
+
+    def _reduce_bf16(self, a, b):
+        """On the side stream: cast -> all-reduce(bf16) -> widen, stream-ordered (the collective is enqueued synchronously with
+        respect to this stream, so the widening kernel runs after it). The staging buffer mirrors the gradient buffer."""
+        L = _lib.load()
+        if self._stage is None:
+            self._stage = torch.empty(self.flat_g.numel(), dtype=torch.bfloat16, device=self.flat_g.device)
+        sp = ctypes.c_void_p(self.stream.cuda_stream)
+        n = b - a
+        check(L.mmsa_cast_f32(_lib.MMSA_BF16, ptr(self.flat_g[a:b]), ptr(self._stage[a:b]), n, sp), "mmsa_cast_f32")
+        dist.all_reduce(self._stage[a:b], op=dist.ReduceOp.SUM, group=self.group)
+        check(L.mmsa_widen_bf16(ptr(self._stage[a:b]), ptr(self.flat_g[a:b]), n, sp), "mmsa_widen_bf16")
 
     def begin_step(self):
         self.issued = []
@@ -269,7 +289,10 @@ class FusedTrainStep:
         # wait for whole CUs; MMSA_G2_CUS=<n> caps the GEMM grid to leave some free — but the planner's tile counts are exact
         # multiples of 256 CUs (BERT-base: 768 tiles = 3 rounds), and measured on one MI355X a cap of 248 / 240 / 224 costs
         # 5.3 % / 5.0 % / 12 % of the WHOLE step, forward included (tools/exp_streams.sh). Left to the env.)
-        self.reducer = GradReducer(self.state.flat_g, bucket_bytes) if self.world > 1 else None
+        # gradient payload of the all-reduce: MMSA_GRAD_PAYLOAD=fp32 | bf16 (default fp32: bit-identical sums on every rank in
+        # rank order independent precision; bf16 halves the bytes on xGMI — DESIGN.md §6)
+        payload = os.environ.get("MMSA_GRAD_PAYLOAD", "fp32")
+        self.reducer = GradReducer(self.state.flat_g, bucket_bytes, payload=payload) if self.world > 1 else None
         if self.world > 1:  # identical replicas: parameters and BN buffers from rank 0
             dist.broadcast(self.state.flat_w, 0)
             dist.broadcast(self.state.flat_bn, 0)
