@@ -69,6 +69,10 @@ struct GemmParams {
   // filled by the MFMA launcher: byte extents of the A / B views for the buffer-descriptor staging path
   unsigned a_bytes, b_bytes;
   int use_srd;
+  // fp8 (e4m3) operands (gemm_fp8.hip; the persistent kernel's NT instantiation): A / B hold e4m3 BYTES, K / lda / ldb are given
+  // in 2-byte units (K = values / 2), the result is scaled by scale_a[0] * scale_b[0] (device scalars). null: bf16 operands.
+  const float* scale_a;
+  const float* scale_b;
   // optional in-kernel timing record {min start, max end} in s_memrealtime ticks (100 MHz), filled by the MFMA kernels
   // and the split-K reducer when non-null (bench.py roofline: HIP event pairs add ~12 us of queue drain per launch)
   unsigned long long* stamp;

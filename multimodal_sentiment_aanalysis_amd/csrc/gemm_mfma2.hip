@@ -106,7 +106,10 @@ __device__ __forceinline__ bf16x8 lds_rd_tr(unsigned addr) {  // k rows kb..kb+3
 // WM = wave rows: 4 -> 256-row tile, waves 4(M) x 2(N); 2 -> 128-row tile, waves 2(M) x 4(N) (twice the tiles for
 // the mid-size convolutions: M = 12544 / 3136 gives only 49 / 13 row tiles of 256). NJ = 16-column MFMA tiles per wave:
 // BN = NJ * 16 * (8 / WM).
-template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER>
+// FP8: the operands are e4m3 bytes (NT only): a K step of 64 two-byte slots is 128 fp8 values in the SAME LDS image, every
+// 16-byte fragment read feeds two v_mfma_f32_16x16x32_fp8_fp8 (bytes 0-7, 8-15: A and B share the slot -> k assignment, so
+// every k meets its partner once), and the epilogue scales by scale_a * scale_b. Half the L2->LDS bytes per FLOP.
+template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) {
   // The body is compiled in the device pass only: hipcc's HOST pass (ROCm 7.2) silently fails to instantiate this
   // template when it sees the body (no diagnostic, the launch stub stays an undefined symbol of the .so).
@@ -369,8 +372,16 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int r16 = lane & 15, g4 = lane >> 4;
+  float fp8_alpha = 1.f;
+  if constexpr (FP8) fp8_alpha = p.scale_a[0] * p.scale_b[0];
   auto epilogue = [&]() __attribute__((always_inline)) -> int {  // returns the store units it issued (0: it drained the queue)
     const int mb = C.m0 + wm * 64 + r16, nb = C.n0 + wn * (NJ * 16) + 4 * g4;
+    if constexpr (FP8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] *= fp8_alpha;
+    }
     if (s.split_k > 1) {  // raw fp32 partials -> slab sp
       const long slab = (long)C.sp * eM * eN;
 #pragma unroll
@@ -646,6 +657,16 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       if constexpr (NJ > 3) fb[3] = lds_rd_tr<kk * 8192>(offB[3] + so);
     }
   };
+  auto mma1 = [&](const bf16x8& fbj, const bf16x8& fai, f32x4 c) __attribute__((always_inline)) -> f32x4 {
+    if constexpr (FP8) {
+      typedef __attribute__((ext_vector_type(2))) long i64x2_;
+      const i64x2_ b2 = __builtin_bit_cast(i64x2_, fbj), a2 = __builtin_bit_cast(i64x2_, fai);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[0], a2[0], c, 0, 0, 0);
+      return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[1], a2[1], c, 0, 0, 0);
+    } else {
+      return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbj, fai, c, 0, 0, 0);
+    }
+  };
   // column sums of A on the matrix pipe: D[n][m] = sum_k 1 * A[m][k] with an all-ones operand in place of the B fragment
   auto mma_colsum = [&](const bf16x8(&fa)[4]) __attribute__((always_inline)) {
     if constexpr (GCOLSUM) {
@@ -662,7 +683,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j) acc[i][j] = mma1(fb[j], fa[i], acc[i][j]);
     mma_colsum(fa);
     __builtin_amdgcn_s_setprio(0);
   };
@@ -681,7 +702,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     auto one = [&](auto idx_c) __attribute__((always_inline)) {
       constexpr int idx = decltype(idx_c)::value;
       constexpr int i = idx / NJ, j = idx % NJ;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      acc[i][j] = mma1(fb[j], fa[i], acc[i][j]);
       if constexpr (idx % GAP == 1 % GAP && P0 + idx / GAP < P1) {
         __builtin_amdgcn_sched_barrier(0);
         dma_piece(stage, std::integral_constant<int, P0 + idx / GAP>{});
@@ -811,6 +832,7 @@ static void g2_extents(const GemmParams& p, long* ea, long* eb) {
 
 bool gemm2_eligible(const GemmParams& p) {
   if (p.gather < 0 || p.gather > 2) return false;
+  if (p.scale_a && (p.gather || p.a_kmajor || p.b_kmajor || !p.scale_b)) return false;  // fp8 operands: NT only
   if (p.K % G2_BK) return false;
   if (p.N % 4) return false;
   if (p.a_kmajor && (p.M % 8)) return false;
@@ -938,15 +960,15 @@ static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
   return plan;
 }
 
-template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER>
+template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8 = false>
 static int g2_launch_t(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER>,
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER>), dim3(grid), dim3(512), G2_LDS, st, p, s);
+  hipLaunchKernelGGL((gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8>), dim3(grid), dim3(512), G2_LDS, st, p, s);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
@@ -958,6 +980,7 @@ static int g2_launch_nj(const GemmParams& p, const G2Sched& s, int grid, hipStre
     return g2_launch_t<WM, NJ, false, true, 1>(p, s, grid, st);
   }
   if (p.gather == 2) return g2_launch_t<WM, NJ, true, true, 2>(p, s, grid, st);
+  if (!p.a_kmajor && !p.b_kmajor && p.scale_a) return g2_launch_t<WM, NJ, false, false, 0, true>(p, s, grid, st);
   if (!p.a_kmajor && !p.b_kmajor) return g2_launch_t<WM, NJ, false, false, 0>(p, s, grid, st);
   if (!p.a_kmajor && p.b_kmajor) return g2_launch_t<WM, NJ, false, true, 0>(p, s, grid, st);
   if (p.a_kmajor && p.b_kmajor) return g2_launch_t<WM, NJ, true, true, 0>(p, s, grid, st);
