@@ -124,6 +124,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
     bc2_sqrt = norm_clip[3];
   }
   const float coef = clip * grad_scale;
+  // loop invariants, explicitly: with the corrections coming from memory the compiler no longer treats lr / bc1 as a uniform
+  // scalar and redid both divisions per element (770 us instead of 630 for 135.6 M parameters)
+  const float step_size = lr / bc1, inv_bc2 = 1.f / bc2_sqrt, decay = 1.f - lr * wd, omb1 = 1.f - b1, omb2 = 1.f - b2;
   const long n4 = n / 4;
   // every stream is touched once per step (540 MB each: nothing survives in L2 / MALL until its next use), so all
   // fp32 accesses are non-temporal; two independent float4 groups per thread keep 8 loads in flight
@@ -131,10 +134,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
     gv = gv * coef;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      wv[e] *= 1.f - lr * wd;
-      mv[e] = b1 * mv[e] + (1.f - b1) * gv[e];
-      vv[e] = b2 * vv[e] + (1.f - b2) * gv[e] * gv[e];
-      wv[e] -= (lr / bc1) * mv[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
+      wv[e] *= decay;
+      mv[e] = b1 * mv[e] + omb1 * gv[e];
+      vv[e] = b2 * vv[e] + omb2 * gv[e] * gv[e];
+      wv[e] -= step_size * mv[e] / (sqrtf(vv[e]) * inv_bc2 + eps);
     }
   };
   auto ld = [&](const float* q, long i) __attribute__((always_inline)) -> f32x4 { return __builtin_nontemporal_load((const f32x4*)(q + i * 4)); };
@@ -163,10 +166,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long i = n4 * 4 + threadIdx.x;
-    float wv = w[i] * (1.f - lr * wd);
+    float wv = w[i] * decay;
     const float gv = g[i] * coef;
-    const float mv = b1 * m[i] + (1.f - b1) * gv, vv = b2 * v[i] + (1.f - b2) * gv * gv;
-    wv -= (lr / bc1) * mv / (sqrtf(vv) / bc2_sqrt + eps);
+    const float mv = b1 * m[i] + omb1 * gv, vv = b2 * v[i] + omb2 * gv * gv;
+    wv -= step_size * mv / (sqrtf(vv) * inv_bc2 + eps);
     w[i] = wv; m[i] = mv; v[i] = vv;
     if (w16) w16[i] = (bf16)wv;
   }
