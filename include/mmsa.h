@@ -102,10 +102,11 @@ int mmsa_gemm(const mmsa_gemm_desc* d, int32_t impl, void* stream);
  * through autograd). Returns MMSA_ERR_UNSUPPORTED (3) when the problems cannot be grouped; nothing is launched then. */
 int mmsa_gemm_group(const mmsa_gemm_desc* d, int32_t n, void* stream);
 /* fp8 (OCP e4m3, the gfx950 format) path of BASELINE.json configs[4]: mmsa_fp8_quantize turns a contiguous bf16 tensor (n % 8 == 0)
- * into e4m3 bytes with a per-tensor scale = amax / 448 (device float; amax_ws: 4 bytes of device scratch); mmsa_gemm_fp8 is the
+ * into e4m3 bytes with a per-tensor scale = amax / 448 (device float; amax_ws: mmsa_fp8_quantize_ws_bytes() of device scratch); mmsa_gemm_fp8 is the
  * NT GEMM of mmsa_gemm on such operands (desc->A / B: e4m3 bytes, k-contiguous rows, lda / ldb in bytes; K % 128 == 0, no
  * gather / split): C = epilogue(scale_a * scale_b * A B^T), fp32 accumulation in v_mfma_f32_16x16x32_fp8_fp8, bf16 (or fp32)
  * output. Returns 3 (unsupported) for shapes it does not take. */
+size_t mmsa_fp8_quantize_ws_bytes(void);
 int mmsa_fp8_quantize(const void* x_bf16, int64_t n, void* out_e4m3, float* scale, void* amax_ws, void* stream);
 int mmsa_gemm_fp8(const mmsa_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream);
 

@@ -96,6 +96,7 @@ def _declare(L):
         "mmsa_gemm_ws_bytes": (sz, [i32, i32, i32]),
         "mmsa_gemm": (ctypes.c_int, [ctypes.POINTER(GemmDesc), i32, vp]),
         "mmsa_gemm_group": (ctypes.c_int, [ctypes.POINTER(GemmDesc), i32, vp]),
+        "mmsa_fp8_quantize_ws_bytes": (sz, []),
         "mmsa_fp8_quantize": (ctypes.c_int, [vp, i64, vp, vp, vp, vp]),
         "mmsa_gemm_fp8": (ctypes.c_int, [ctypes.POINTER(GemmDesc), vp, vp, vp]),
         "mmsa_layernorm_fwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),

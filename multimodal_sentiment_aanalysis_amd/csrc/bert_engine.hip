@@ -80,7 +80,7 @@ struct BertWs {
   void *bufA, *bufB, *bufC, *bufD, *bufI, *bufQ;
   void* ones8;  // [B*S][8] bf16 ones (grouped bias gradients, engine_common.h)
   void *q_act, *q_w;     // fp8 mode: e4m3 copies of a Linear's input ([B*S][max(H, I)]) and weight ([max N*K])
-  float* q_scales;       // fp8 mode: [0] activation scale, [1] weight scale, [2] amax scratch (as uint)
+  float* q_scales;       // fp8 mode: [0] activation scale, [1] weight scale, [16...] the quantizer's partial-maximum scratch
   size_t colws_bytes;
   float *splitk, *colws, *lnws, *attnws;
   size_t splitk_bytes;
@@ -133,7 +133,7 @@ static BertWs bert_ws(const mmsa_bert_cfg& c, void* base) {
   if (c.dtype == MMSA_FP8) {
     w.q_act = b.take(M * (H > I ? H : I));
     w.q_w = b.take((size_t)I * H > 3 * H * H ? (size_t)I * H : 3 * H * H);
-    w.q_scales = (float*)b.take(64);
+    w.q_scales = (float*)b.take(64 + fp8_quantize_ws_bytes());
   }
   w.lnws = (float*)b.take(layernorm_bwd_ws_bytes((int)H));
   w.attnws = (float*)b.take(attention_bwd_ws_bytes(c.batch, c.seq, c.heads));

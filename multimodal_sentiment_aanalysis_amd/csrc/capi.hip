@@ -67,6 +67,7 @@ int mmsa_gemm_group(const mmsa_gemm_desc* d, int32_t n, void* stream) {
   return gemm_bf16_launch_group(ps, cs, n, (hipStream_t)stream);
 }
 
+size_t mmsa_fp8_quantize_ws_bytes(void) { return fp8_quantize_ws_bytes(); }
 int mmsa_fp8_quantize(const void* x_bf16, int64_t n, void* out_e4m3, float* scale, void* amax_ws, void* stream) {
   return fp8_quantize(x_bf16, n, out_e4m3, scale, (unsigned*)amax_ws, (hipStream_t)stream);
 }

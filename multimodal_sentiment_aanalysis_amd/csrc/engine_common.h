@@ -140,8 +140,8 @@ struct Eng {
     p.bias = bias; p.act = act; p.C2 = pre; p.ldc2 = N; p.add = add; p.ldadd = ldadd;
     p.c2_gelu_grad = (pre && act == MMSA_ACT_GELU) ? pre_is_gelu_grad : 0;
     if (!gemm_fp8_eligible(p)) return MMSA_ERR_UNSUPPORTED;
-    RET_IF(fp8_quantize(x, (long)M * K, q_act, q_scales, (unsigned*)(q_scales + 2), st));
-    RET_IF(fp8_quantize(W, (long)N * K, q_w, q_scales + 1, (unsigned*)(q_scales + 2), st));
+    RET_IF(fp8_quantize(x, (long)M * K, q_act, q_scales, (unsigned*)(q_scales + 16), st));
+    RET_IF(fp8_quantize(W, (long)N * K, q_w, q_scales + 1, (unsigned*)(q_scales + 16), st));
     return gemm_fp8_launch(p, q_scales, q_scales + 1, st);
   }
   // fp32 SIMT GEMMs of the fusion head have M = batch rows: a handful of workgroups each walking the whole K serially.

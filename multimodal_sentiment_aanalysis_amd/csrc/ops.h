@@ -7,6 +7,7 @@
 int gemm_bf16_simt_launch(const GemmParams& p, hipStream_t st);
 
 // gemm_fp8.hip
+size_t fp8_quantize_ws_bytes();
 int fp8_quantize(const void* x_bf16, long n, void* out_e4m3, float* scale, unsigned* amax_ws, hipStream_t st);
 bool gemm_fp8_eligible(const GemmParams& p);
 int gemm_fp8_launch(const GemmParams& p, const float* scale_a, const float* scale_b, hipStream_t st);

@@ -71,7 +71,7 @@ def fp8_quantize(x):
     L = _lib.load()
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     scale = torch.empty(1, dtype=torch.float32, device=x.device)
-    amax = torch.empty(1, dtype=torch.int32, device=x.device)
+    amax = torch.empty(L.mmsa_fp8_quantize_ws_bytes(), dtype=torch.uint8, device=x.device)
     check(L.mmsa_fp8_quantize(ptr(x), x.numel(), ptr(out), ptr(scale), ptr(amax), stream_ptr()), "mmsa_fp8_quantize")
     return out, scale
 
