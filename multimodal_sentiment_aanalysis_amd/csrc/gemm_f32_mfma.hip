@@ -27,6 +27,9 @@
 #define FBK 16
 #define FLD 130
 #define F_LDS_FLOATS (4 * 32 * 36 > 2 * FBK * FLD ? 4 * 32 * 36 : 2 * FBK * FLD)
+#ifndef F32_WPS
+#define F32_WPS 4  // waves per SIMD the register budget is set for (4 = 4 workgroups per CU; measured against 2 and 3)
+#endif
 #define FSPLIT_GRAN 32  // split-K partition granularity = the SIMT kernel's K step (identical slabs -> identical sums)
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -58,7 +61,7 @@ static F32Plan f32_plan(const GemmParams& p) {
 }
 
 template <int AMODE, int BMODE>
-__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, F32_WPS) void gemm_f32_mfma_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float lds[F_LDS_FLOATS];  // A tile | B tile; reused by the epilogue images
   float* const As = lds;
   float* const Bs = lds + FBK * FLD;
@@ -310,8 +313,9 @@ int gemm_f32_mfma_launch(const GemmParams& pin, hipStream_t st) {
   if (p.ws && p.ws_bytes > 0 && !(p.N % 4)) {
     const long tiles = (long)cdiv(p.M, FBM) * cdiv(p.N, FBN);
     int split = 1;
-    if (tiles < 512) {
-      split = (int)((512 + tiles - 1) / tiles);
+    static const int target = [] { const char* v = getenv("MMSA_F32_TARGET_WGS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 768; }();
+    if (tiles < target) {
+      split = (int)((target + tiles - 1) / tiles);
       const int maxs = p.K / 256;
       if (split > maxs) split = maxs;
       if (split > 32) split = 32;
