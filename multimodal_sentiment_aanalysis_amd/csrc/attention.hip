@@ -499,6 +499,237 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_rc_kernel(const bf16* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fp32 on the matrix cores
+// The exact mode's attention (fp32 storage, S <= 128, S % 16 == 0) on v_mfma_f32_16x16x4_f32 — an exact-fp32 fmaf chain per
+// output, like the fp32 GEMM — instead of the VALU kernels below (27 of the exact step's 125 ms at B = 64). Same structure as
+// the bf16 kernels: one workgroup per (batch, head), 4 waves; a wave owns 16 queries at a time with the whole score row in
+// registers (lane = one query column, 4 consecutive keys per accumulator register group); products are issued with the
+// "row" operand in the A slot so the probability tile is directly the next product's B-slot operand: for the k step that
+// takes register r, lane group g supplies key 16 t + 4 g + r, and the V / K / dO / Q operand reads exactly that row.
+// The backward is the recompute form (attn_bwd_mfma_rc_kernel): per-query max / 1/sum / delta in LDS, key-owned phase 2
+// recomputes the transposed tiles. LDS images are [S][66] floats (stride 66: the 16-rows x 4-columns operand reads are
+// conflict-free). P is NOT rounded here (fp32 storage: the forward multiplies V by the fp32 probability).
+#define FA_LD 66
+template <int NT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
+                                                                float* __restrict__ ctx, int heads, float scale) {
+  constexpr int S = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Kt = (float*)smem;
+  float* Vt = Kt + S * FA_LD;
+  float* mb = Vt + S * FA_LD;
+  const int Hd = heads * HD, ld = 3 * Hd;
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const float* base = qkv + (long)b * S * ld + h * HD;
+  for (int c = tid; c < S * 16; c += 256) {  // float4 chunks of the K and V rows
+    const int row = c >> 4, c4 = (c & 15) * 4;
+    const f32x4 kv = *(const f32x4*)(base + (long)row * ld + Hd + c4), vv = *(const f32x4*)(base + (long)row * ld + 2 * Hd + c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { Kt[row * FA_LD + c4 + e] = kv[e]; Vt[row * FA_LD + c4 + e] = vv[e]; }
+  }
+  for (int i = tid; i < S; i += 256) mb[i] = (mask == nullptr || mask[(long)b * S + i] != 0.f) ? 0.f : 1.f;
+  __syncthreads();
+  for (int qt = wave; qt < NT; qt += 4) {
+    const int q0 = qt * 16;
+    float qf[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) qf[ks] = base[(long)(q0 + r16) * ld + 4 * ks + g];
+    f32x4 s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Kt[(16 * t + r16) * FA_LD + 4 * ks + g], qf[ks], s[t], 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = mb[16 * t + 4 * g + r] != 0.f ? MASK_NEG : s[t][r] * scale;
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[t][r] - mx);
+        s[t][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = s[t][r] * inv;
+        const float* vrow = Vt + (16 * t + 4 * g + r) * FA_LD + r16;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[16 * dt], pv, o[dt], 0, 0, 0);
+      }
+    float* orow = ctx + ((long)b * S + q0 + r16) * Hd + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) *(f32x4*)(orow + 16 * dt + 4 * g) = o[dt];
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void attn_bwd_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
+                                                                const float* __restrict__ dctx, float* __restrict__ dqkv, int heads,
+                                                                float scale) {
+  constexpr int S = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Kt = (float*)smem;
+  float* Vt = Kt + S * FA_LD;
+  float* Qt = Vt + S * FA_LD;
+  float* Dt = Qt + S * FA_LD;
+  float* mb = Dt + S * FA_LD;
+  float* rmx = mb + S;
+  float* rinv = rmx + S;
+  float* rdel = rinv + S;
+  const int Hd = heads * HD, ld = 3 * Hd;
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const float* base = qkv + (long)b * S * ld + h * HD;
+  const float* dbase = dctx + (long)b * S * Hd + h * HD;
+  for (int c = tid; c < S * 16; c += 256) {
+    const int row = c >> 4, c4 = (c & 15) * 4;
+    const f32x4 qv = *(const f32x4*)(base + (long)row * ld + c4), kv = *(const f32x4*)(base + (long)row * ld + Hd + c4);
+    const f32x4 vv = *(const f32x4*)(base + (long)row * ld + 2 * Hd + c4), dv = *(const f32x4*)(dbase + (long)row * Hd + c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      Qt[row * FA_LD + c4 + e] = qv[e]; Kt[row * FA_LD + c4 + e] = kv[e];
+      Vt[row * FA_LD + c4 + e] = vv[e]; Dt[row * FA_LD + c4 + e] = dv[e];
+    }
+  }
+  for (int i = tid; i < S; i += 256) mb[i] = (mask == nullptr || mask[(long)b * S + i] != 0.f) ? 0.f : 1.f;
+  __syncthreads();
+
+  // ---- phase 1: query-owned. lane: query q0 + r16, keys 16 t + 4 g + r
+  for (int qt = wave; qt < NT; qt += 4) {
+    const int q0 = qt * 16;
+    f32x4 s[NT], dp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s[t] = f32x4{0, 0, 0, 0};
+      dp[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int o = 4 * ks + g;
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Kt[(16 * t + r16) * FA_LD + o], Qt[(q0 + r16) * FA_LD + o], s[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vt[(16 * t + r16) * FA_LD + o], Dt[(q0 + r16) * FA_LD + o], dp[t], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = mb[16 * t + 4 * g + r] != 0.f ? MASK_NEG : s[t][r] * scale;
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[t][r] - mx);
+        s[t][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    float delta = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[t][r] *= inv;
+        delta += s[t][r] * dp[t][r];
+      }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    if (g == 0) { rmx[q0 + r16] = mx; rinv[q0 + r16] = inv; rdel[q0 + r16] = delta; }
+    // dQ[q][d] = sum_key dS[q][key] K[key][d]
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ds = s[t][r] * (dp[t][r] - delta) * scale;
+        const float* krow = Kt + (16 * t + 4 * g + r) * FA_LD + r16;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(krow[16 * dt], ds, o[dt], 0, 0, 0);
+      }
+    float* orow = dqkv + ((long)b * S + q0 + r16) * ld + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) *(f32x4*)(orow + 16 * dt + 4 * g) = o[dt];
+  }
+  __syncthreads();
+
+  // ---- phase 2: key-owned. lane: key k0 + r16, queries 16 t + 4 g + r (recomputed transposed tiles)
+  for (int kt = wave; kt < NT; kt += 4) {
+    const int k0 = kt * 16;
+    float kf[16], vf[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) { kf[ks] = Kt[(k0 + r16) * FA_LD + 4 * ks + g]; vf[ks] = Vt[(k0 + r16) * FA_LD + 4 * ks + g]; }
+    const bool masked = mb[k0 + r16] != 0.f;
+    f32x4 dv[4], dk[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dv[dt] = f32x4{0, 0, 0, 0}; dk[dt] = f32x4{0, 0, 0, 0}; }
+#pragma unroll 2
+    for (int t = 0; t < NT; ++t) {
+      f32x4 sc = {0, 0, 0, 0}, dpv = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int o = 4 * ks + g;
+        sc = __builtin_amdgcn_mfma_f32_16x16x4f32(Qt[(16 * t + r16) * FA_LD + o], kf[ks], sc, 0, 0, 0);    // [query 16t+4g+r][key k0+r16]
+        dpv = __builtin_amdgcn_mfma_f32_16x16x4f32(Dt[(16 * t + r16) * FA_LD + o], vf[ks], dpv, 0, 0, 0);  // dP, same layout
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = 16 * t + 4 * g + r;
+        const float v = masked ? MASK_NEG : sc[r] * scale;
+        const float pr = __expf(v - rmx[q]) * rinv[q];
+        const float ds = pr * (dpv[r] - rdel[q]) * scale;
+        const float* drow = Dt + q * FA_LD + r16;
+        const float* qrow = Qt + q * FA_LD + r16;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(drow[16 * dt], pr, dv[dt], 0, 0, 0);  // dV[key][d] += P[q][key] dO[q][d]
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qrow[16 * dt], ds, dk[dt], 0, 0, 0);  // dK[key][d] += dS[q][key] Q[q][d]
+        }
+      }
+    }
+    float* krow = dqkv + ((long)b * S + k0 + r16) * ld + Hd + h * HD;
+    float* vrow = krow + Hd;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      *(f32x4*)(krow + 16 * dt + 4 * g) = dk[dt];
+      *(f32x4*)(vrow + 16 * dt + 4 * g) = dv[dt];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ SIMT kernels
 // 4 lanes per row (query or key); lane `sub` owns head dims [16 sub, 16 sub + 16).
 template <typename T>
@@ -736,11 +967,55 @@ static int attn_bwd_mfma_rc_nt(const void* qkv, const float* mask, const void* d
   return MMSA_OK;
 }
 
+static bool attn_f32_mfma_on() {
+  static const bool off = [] { const char* v = getenv("MMSA_F32_SIMT"); return v && atoi(v) != 0; }();
+  return !off;
+}
+template <int NT>
+static int attn_fwd_f32_nt(const void* qkv, const float* mask, void* ctx, int B, int heads, hipStream_t st) {
+  constexpr int S = NT * 16;
+  const size_t lds = (size_t)2 * S * FA_LD * 4 + S * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_f32_mfma_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_fwd_f32_mfma_kernel<NT>, dim3(B * heads), dim3(256), lds, st, (const float*)qkv, mask, (float*)ctx, heads,
+                     0.125f);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+template <int NT>
+static int attn_bwd_f32_nt(const void* qkv, const float* mask, const void* dctx, void* dqkv, int B, int heads, hipStream_t st) {
+  constexpr int S = NT * 16;
+  const size_t lds = (size_t)4 * S * FA_LD * 4 + (size_t)4 * S * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_f32_mfma_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_f32_mfma_kernel<NT>, dim3(B * heads), dim3(256), lds, st, (const float*)qkv, mask, (const float*)dctx,
+                     (float*)dqkv, heads, 0.125f);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
 // impl: 0 = fp32 storage (SIMT), 1 = bf16 storage MFMA, 2 = bf16 storage SIMT (cross-check)
 int attention_fwd(int impl, const void* qkv, const float* mask, void* ctx, int B, int S, int heads, int head_dim,
                   hipStream_t st) {
   if (head_dim != HD || S < 1) return MMSA_ERR_UNSUPPORTED;
-  if (impl == 0) return attn_fwd_simt<float>(qkv, mask, ctx, B, S, heads, st);
+  if (impl == 0) {  // fp32 storage: the fp32-MFMA kernel for S = 16 .. 128 in steps of 16, else (or MMSA_F32_SIMT=1) the VALU one
+    if (attn_f32_mfma_on() && S % 16 == 0 && S <= 128) switch (S / 16) {
+      case 1: return attn_fwd_f32_nt<1>(qkv, mask, ctx, B, heads, st);
+      case 2: return attn_fwd_f32_nt<2>(qkv, mask, ctx, B, heads, st);
+      case 3: return attn_fwd_f32_nt<3>(qkv, mask, ctx, B, heads, st);
+      case 4: return attn_fwd_f32_nt<4>(qkv, mask, ctx, B, heads, st);
+      case 6: return attn_fwd_f32_nt<6>(qkv, mask, ctx, B, heads, st);
+      case 8: return attn_fwd_f32_nt<8>(qkv, mask, ctx, B, heads, st);
+      default: break;
+    }
+    return attn_fwd_simt<float>(qkv, mask, ctx, B, S, heads, st);
+  }
   if (impl == 2) return attn_fwd_simt<bf16>(qkv, mask, ctx, B, S, heads, st);
   if (S % 16 || S > 256) return attn_fwd_simt<bf16>(qkv, mask, ctx, B, S, heads, st);
   switch (S / 16) {
@@ -759,7 +1034,18 @@ int attention_fwd(int impl, const void* qkv, const float* mask, void* ctx, int B
 int attention_bwd(int impl, const void* qkv, const float* mask, const void* dctx, void* dqkv, float* ws, int B, int S,
                   int heads, int head_dim, hipStream_t st) {
   if (head_dim != HD || S < 1) return MMSA_ERR_UNSUPPORTED;
-  if (impl == 0) return attn_bwd_simt<float>(qkv, mask, dctx, dqkv, ws, B, S, heads, st);
+  if (impl == 0) {
+    if (attn_f32_mfma_on() && S % 16 == 0 && S <= 128) switch (S / 16) {
+      case 1: return attn_bwd_f32_nt<1>(qkv, mask, dctx, dqkv, B, heads, st);
+      case 2: return attn_bwd_f32_nt<2>(qkv, mask, dctx, dqkv, B, heads, st);
+      case 3: return attn_bwd_f32_nt<3>(qkv, mask, dctx, dqkv, B, heads, st);
+      case 4: return attn_bwd_f32_nt<4>(qkv, mask, dctx, dqkv, B, heads, st);
+      case 6: return attn_bwd_f32_nt<6>(qkv, mask, dctx, dqkv, B, heads, st);
+      case 8: return attn_bwd_f32_nt<8>(qkv, mask, dctx, dqkv, B, heads, st);
+      default: break;
+    }
+    return attn_bwd_simt<float>(qkv, mask, dctx, dqkv, ws, B, S, heads, st);
+  }
   if (impl == 2) return attn_bwd_simt<bf16>(qkv, mask, dctx, dqkv, ws, B, S, heads, st);
   switch (S) {
     case 16: return attn_bwd_mfma_nt<1>(qkv, mask, dctx, dqkv, B, heads, st);

@@ -49,13 +49,13 @@ static F32Plan f32_plan(const GemmParams& p) {
   if (k16 && taps_ok && !((size_t)p.A & 15)) {
     if (p.gather == 1 && !p.a_kmajor) pl.amode = F_GATHER1;
     else if (p.gather != 1 && !p.a_kmajor && !(p.lda % 4)) pl.amode = F_KCONTIG;
-    else if (p.a_kmajor && !(p.lda % 2) && !(p.M % 2)) pl.amode = F_XCONTIG;
+    else if (p.a_kmajor && !(p.lda % 4) && !(p.M % 4)) pl.amode = F_XCONTIG;
   }
   if (k16 && taps_ok && !((size_t)p.B & 15)) {
-    if (p.gather == 2) { if (!(p.g.cper % 2) && !(p.N % 2)) pl.bmode = F_GATHER2; }
+    if (p.gather == 2) { if (!(p.g.cper % 4) && !(p.N % 4)) pl.bmode = F_GATHER2; }
     else if (!p.b_kmajor && !(p.ldb % 4)) pl.bmode = F_KCONTIG;
-    else if (p.b_kmajor && p.gather == 1) { if (!(p.ldb % 2) && !(p.N % 2) && !(p.b_tap_stride % 2) && !(p.b_tap_stride_y % 2)) pl.bmode = F_GATHER1_B; }
-    else if (p.b_kmajor && !(p.ldb % 2) && !(p.N % 2)) pl.bmode = F_XCONTIG;
+    else if (p.b_kmajor && p.gather == 1) { if (!(p.ldb % 4) && !(p.N % 4) && !(p.b_tap_stride % 4) && !(p.b_tap_stride_y % 4)) pl.bmode = F_GATHER1_B; }
+    else if (p.b_kmajor && !(p.ldb % 4) && !(p.N % 4)) pl.bmode = F_XCONTIG;
   }
   return pl;
 }
@@ -92,10 +92,10 @@ __global__ __launch_bounds__(256, F32_WPS) void gemm_f32_mfma_kernel(GemmParams 
   // ---- per-thread staging maps -------------------------------------------------------------------------------------
   // k-contiguous storage: thread -> rows (tid >> 2) + 64 j (j = 0, 1), 4 consecutive k at (tid & 3) * 4: the 4 lanes of a
   //   row read its 64 contiguous bytes; the LDS writes (4 scalars per row into 4 k-rows) are conflict-free at stride 130.
-  // x-contiguous storage (m or n along memory): thread -> k-row tid >> 4, columns 2 (tid & 15) + 32 j (j = 0..3): 16 lanes
-  //   read 128 contiguous bytes; one ds_write_b64 per pair.
+  // x-contiguous storage (m or n along memory): thread -> k-row tid >> 4, columns 4 (tid & 15) + 64 j (j = 0, 1): 16 lanes
+  //   read 256 contiguous bytes per load; two ds_write_b64 per float4 (rows are 8-byte aligned at stride 130).
   const int kc_row = tid >> 2, kc_k = (tid & 3) * 4;
-  const int xc_k = tid >> 4, xc_x = 2 * (tid & 15);
+  const int xc_k = tid >> 4, xc_x = 4 * (tid & 15);  // x-contiguous: 16 lanes x 16 B = 256 contiguous bytes of a k-row, twice (+64)
   float ra[8], rb[8];
   RowPix apix[2];
   if constexpr (AMODE == F_GATHER1) {
@@ -125,11 +125,11 @@ __global__ __launch_bounds__(256, F32_WPS) void gemm_f32_mfma_kernel(GemmParams 
     } else if constexpr (AMODE == F_XCONTIG) {
       const int k = k0 + xc_k;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int m = m0 + xc_x + 32 * j;
-        f32x2 v = {0.f, 0.f};
-        if (m < p.M && k < kend) v = *(const f32x2*)(A + (long)k * p.lda + m);
-        ra[2 * j] = v[0]; ra[2 * j + 1] = v[1];
+      for (int j = 0; j < 2; ++j) {
+        const int m = m0 + xc_x + 64 * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < p.M && k < kend) v = *(const f32x4*)(A + (long)k * p.lda + m);
+        ra[4 * j] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3];
       }
     } else {
 #pragma unroll
@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256, F32_WPS) void gemm_f32_mfma_kernel(GemmParams 
         for (int r = 0; r < 4; ++r) As[(kc_k + r) * FLD + kc_row + 64 * j] = ra[4 * j + r];
     } else if constexpr (AMODE == F_XCONTIG) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *(f32x2*)&As[xc_k * FLD + xc_x + 32 * j] = f32x2{ra[2 * j], ra[2 * j + 1]};
+      for (int j = 0; j < 2; ++j) {
+        *(f32x2*)&As[xc_k * FLD + xc_x + 64 * j] = f32x2{ra[4 * j], ra[4 * j + 1]};
+        *(f32x2*)&As[xc_k * FLD + xc_x + 64 * j + 2] = f32x2{ra[4 * j + 2], ra[4 * j + 3]};
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -174,26 +177,26 @@ __global__ __launch_bounds__(256, F32_WPS) void gemm_f32_mfma_kernel(GemmParams 
         row = (long)c * p.ldb + b_tap_offset(p, ky, kx);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + xc_x + 32 * j;
-        f32x2 v = {0.f, 0.f};
-        if (n < p.N && k < kend) v = *(const f32x2*)(B + row + n);
-        rb[2 * j] = v[0]; rb[2 * j + 1] = v[1];
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + xc_x + 64 * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.N && k < kend) v = *(const f32x4*)(B + row + n);
+        rb[4 * j] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3];
       }
     } else if constexpr (BMODE == F_GATHER2) {  // k-rows are output pixels, columns n = tap * cper + c of the shifted input pixel
       const int k = k0 + xc_k;
       const RowPix px = decompose_pixel(p.g, k, kend);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + xc_x + 32 * j;
-        f32x2 v = {0.f, 0.f};
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + xc_x + 64 * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (n < p.N) {
           const int tap = (int)fd_div((uint32_t)n, p.g.fd_cper), c = n - tap * p.g.cper;
           const int ky = (int)fd_div((uint32_t)tap, p.g.fd_kw), kx = tap - ky * p.g.KW;
           const long s = tap_src(p.g, px, ky, kx);
-          if (s >= 0) v = *(const f32x2*)(B + s + c);
+          if (s >= 0) v = *(const f32x4*)(B + s + c);
         }
-        rb[2 * j] = v[0]; rb[2 * j + 1] = v[1];
+        rb[4 * j] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3];
       }
     } else {
 #pragma unroll
@@ -211,7 +214,10 @@ __global__ __launch_bounds__(256, F32_WPS) void gemm_f32_mfma_kernel(GemmParams 
         for (int r = 0; r < 4; ++r) Bs[(kc_k + r) * FLD + kc_row + 64 * j] = rb[4 * j + r];
     } else if constexpr (BMODE == F_XCONTIG || BMODE == F_GATHER1_B || BMODE == F_GATHER2) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *(f32x2*)&Bs[xc_k * FLD + xc_x + 32 * j] = f32x2{rb[2 * j], rb[2 * j + 1]};
+      for (int j = 0; j < 2; ++j) {
+        *(f32x2*)&Bs[xc_k * FLD + xc_x + 64 * j] = f32x2{rb[4 * j], rb[4 * j + 1]};
+        *(f32x2*)&Bs[xc_k * FLD + xc_x + 64 * j + 2] = f32x2{rb[4 * j + 2], rb[4 * j + 3]};
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -318,7 +324,7 @@ int gemm_f32_mfma_launch(const GemmParams& pin, hipStream_t st) {
       split = (int)((target + tiles - 1) / tiles);
       const int maxs = p.K / 256;
       if (split > maxs) split = maxs;
-      if (split > 32) split = 32;
+      if (split > 256) split = 256;
       while (split > 1 && (long)split * p.M * p.N * (long)sizeof(float) > p.ws_bytes) --split;
       if (split < 1) split = 1;
     }
