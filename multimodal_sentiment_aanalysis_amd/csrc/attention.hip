@@ -511,7 +511,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_rc_kernel(const bf16* __res
 // conflict-free). P is NOT rounded here (fp32 storage: the forward multiplies V by the fp32 probability).
 #define FA_LD 66
 template <int NT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
+__global__ __launch_bounds__(256) void attn_fwd_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
                                                                 float* __restrict__ ctx, int heads, float scale) {
   constexpr int S = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
