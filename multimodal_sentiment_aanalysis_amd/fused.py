@@ -302,6 +302,11 @@ class FusedTrainStep:
         self._image_net = getattr(getattr(model, "encoder", None), "image_net", None)
         if self._image_net is not None and self.device.type == "cuda" and two_streams:
             self._image_net.use_side_stream(True)
+        # optional: the two cross-modal transformers on side streams beside the fusion chain (MMSA_HEAD_STREAMS=1; A/B hook)
+        self._head_streams = None
+        if os.environ.get("MMSA_HEAD_STREAMS", "0") == "1" and hasattr(model, "use_head_streams") and self.device.type == "cuda":
+            model.use_head_streams(True)
+            self._head_streams = model._head_streams
         self._ranges = {id(e): (off, n) for e, off, n in self.state.ranges}
         for e, off, n in self.state.ranges:
             on = self.reducer is not None
@@ -337,6 +342,9 @@ class FusedTrainStep:
         logits.backward(dlogits)
         if self._image_net is not None:
             self._image_net.join()
+        if self._head_streams is not None:  # their backward kernels wrote parameter gradients autograd does not track
+            for st in self._head_streams:
+                torch.cuda.current_stream(self.device).wait_stream(st)
         if self.reducer is not None:
             self.reducer.finish()
         # NaN rule (Trainer.py:74-76): decided on the device from the reduced gradient norm (identical on every rank, so
