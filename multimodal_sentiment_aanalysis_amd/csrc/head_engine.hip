@@ -264,13 +264,23 @@ static int cross_fwd(const HCtx& h, const HeadLayout& L, HeadWs& w, const float*
   const float *q = in[0], *k = in[1], *v = in[2];
   const Eng& e = h.e;
   // packed in-projection: rows [0,E) = Wq, [E,2E) = Wk, [2E,3E) = Wv (torch MultiheadAttention)
-  RET_IF(e.linear_fwd(q, E, h.P(L.mha.inw), h.P(L.mha.inb), w.qp, E, B, E, E));
-  RET_IF(e.linear_fwd(k, E, h.P(L.mha.inw) + (long)E * E, h.P(L.mha.inb) + E, w.kp, E, B * Lk, E, E));
-  RET_IF(e.linear_fwd(v, E, h.P(L.mha.inw) + 2L * E * E, h.P(L.mha.inb) + 2 * E, w.vp, E, B * Lk, E, E));
-  RET_IF(mha_core_fwd(w.qp, E, w.kp, E, w.vp, E, w.ctx, E, w.probs, B, 1, Lk, E, h.c.heads, e.st));
+  // One key (Lk == 1: how the reference's forward calls it, MultimodalModel.py:132-137 unsqueezes [B,256] to a length-1
+  // sequence): softmax over a single key is exactly 1 for every head, so the context IS the projected value — the query /
+  // key projections cannot reach the output (their gradients are exactly zero too, cross_bwd). Two GEMMs + the core skipped.
+  const bool one_key = (Lk == 1);
+  const float* ctx = w.ctx;
+  if (one_key) {
+    RET_IF(e.linear_fwd(v, E, h.P(L.mha.inw) + 2L * E * E, h.P(L.mha.inb) + 2 * E, w.vp, E, B, E, E));
+    ctx = w.vp;
+  } else {
+    RET_IF(e.linear_fwd(q, E, h.P(L.mha.inw), h.P(L.mha.inb), w.qp, E, B, E, E));
+    RET_IF(e.linear_fwd(k, E, h.P(L.mha.inw) + (long)E * E, h.P(L.mha.inb) + E, w.kp, E, B * Lk, E, E));
+    RET_IF(e.linear_fwd(v, E, h.P(L.mha.inw) + 2L * E * E, h.P(L.mha.inb) + 2 * E, w.vp, E, B * Lk, E, E));
+    RET_IF(mha_core_fwd(w.qp, E, w.kp, E, w.vp, E, w.ctx, E, w.probs, B, 1, Lk, E, h.c.heads, e.st));
+  }
   // cat = [query | attn_out]: the out-projection writes straight into the right half
   RET_IF(ew2d(EW_COPY, q, E, nullptr, 0, w.cat, 2 * E, B, E, e.st));
-  RET_IF(e.linear_fwd(w.ctx, E, h.P(L.mha.outw), h.P(L.mha.outb), w.cat + E, 2 * E, B, E, E));
+  RET_IF(e.linear_fwd(ctx, E, h.P(L.mha.outw), h.P(L.mha.outb), w.cat + E, 2 * E, B, E, E));
   RET_IF(h.lin_fwd(L.gate, w.cat, 2 * E, w.g, E, B, MMSA_ACT_SIGMOID));
   RET_IF(gate_mix_fwd(w.g, w.cat, 2 * E, w.cat + E, 2 * E, w.mix, B, E, e.st));
   return layernorm_fwd(MMSA_F32, w.mix, h.P(L.lnw), h.P(L.lnb), out[0], w.mean, w.rstd, B, E, h.c.ln_eps, e.st);
@@ -288,9 +298,26 @@ static int cross_bwd(const HCtx& h, const HeadLayout& L, HeadWs& w, const float*
   RET_IF(ew2d(EW_ADD, w.dcat, 2 * E, w.dqp, E, w.dq2, E, B, E, e.st));           // d query (direct paths)
   RET_IF(ew2d(EW_ADD, w.dcat + E, 2 * E, w.dctx, E, w.dmix, E, B, E, e.st));     // d attn_out
   // out-projection
+  const bool one_key = (Lk == 1);
   if (h.g) {
     RET_IF(e.bias_grad(w.dmix, E, h.G(L.mha.outb), B, E, h.acc));
-    RET_IF(e.linear_wgrad(w.dmix, E, w.ctx, E, h.G(L.mha.outw), B, E, E, h.acc));
+    RET_IF(e.linear_wgrad(w.dmix, E, one_key ? w.vp : w.ctx, E, h.G(L.mha.outw), B, E, E, h.acc));
+  }
+  if (one_key) {
+    // context == projected value (cross_fwd): d(projected value) = d(context); the query / key projections get exactly zero
+    // gradient (softmax over one key: p (dp - p dp) = 0), the key input too; the query only through its direct paths (dq2)
+    RET_IF(e.linear_dgrad(w.dmix, E, h.P(L.mha.outw), w.dvp, E, B, E, E));
+    if (h.g) {
+      if (!h.acc) {  // overwrite mode: the zero gradients must be written
+        if (hipMemsetAsync(h.G(L.mha.inw), 0, (size_t)2 * E * E * sizeof(float), e.st) != hipSuccess) return MMSA_ERR_LAUNCH;
+        if (hipMemsetAsync(h.G(L.mha.inb), 0, (size_t)2 * E * sizeof(float), e.st) != hipSuccess) return MMSA_ERR_LAUNCH;
+      }
+      RET_IF(e.bias_grad(w.dvp, E, h.G(L.mha.inb) + 2 * E, B, E, h.acc));
+      RET_IF(e.linear_wgrad(w.dvp, E, v, E, h.G(L.mha.inw) + 2L * E * E, B, E, E, h.acc));
+    }
+    RET_IF(ew2d(EW_COPY, w.dq2, E, nullptr, 0, din[0], E, B, E, e.st));
+    if (hipMemsetAsync(din[1], 0, (size_t)B * E * sizeof(float), e.st) != hipSuccess) return MMSA_ERR_LAUNCH;
+    return e.linear_dgrad(w.dvp, E, h.P(L.mha.inw) + 2L * E * E, din[2], E, B, E, E);
   }
   RET_IF(e.linear_dgrad(w.dmix, E, h.P(L.mha.outw), w.dctx, E, B, E, E));
   RET_IF(mha_core_bwd(w.qp, E, w.kp, E, w.vp, E, w.probs, w.dctx, E, w.dqp, E, w.dkp, E, w.dvp, E, B, 1, Lk, E, h.c.heads, e.st));
