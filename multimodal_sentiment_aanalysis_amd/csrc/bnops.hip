@@ -330,6 +330,105 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ---- small batches (the fusion head: 64 rows x 128-256 features, fp32) -------------------------------------------------
+// One launch instead of three per direction: a workgroup owns 8 features and all rows (<= BN_SMALL_ROWS), keeps its
+// elements in registers between the statistics and the apply phase.  Same expressions as the streamed kernels (fp32
+// per-lane partial sums, fp64 combine for the forward statistics, fp32 for the backward sums).
+#define BN_SMALL_ROWS 256
+#define BN_SMALL_RPT (BN_SMALL_ROWS / 32)
+__device__ __forceinline__ float bn_dz1(float dy, float xh, float g, float b, float z, int act) {
+  if (act == MMSA_ACT_RELU) return z > 0.f ? dy : 0.f;
+  if (act == MMSA_ACT_GELU) return dy * gelu_erf_grad(xh * g + b);
+  return dy;
+}
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float* __restrict__ mean,
+                                                           float* __restrict__ invstd, float* __restrict__ y, int M, int C,
+                                                           float eps, float momentum, int act) {
+  __shared__ double rs[32][8], rq[32][8];
+  const int cc = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cc;
+  float xs[BN_SMALL_RPT];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < BN_SMALL_RPT; ++i) {
+    const int r = rl + 32 * i;
+    xs[i] = r < M ? x[(long)r * C + c] : 0.f;
+    s += xs[i];
+    q += xs[i] * xs[i];
+  }
+  rs[rl][cc] = s;
+  rq[rl][cc] = q;
+  __syncthreads();
+  double S = 0, Q = 0;
+#pragma unroll 8
+  for (int j = 0; j < 32; ++j) { S += rs[j][cc]; Q += rq[j][cc]; }
+  const double mu = S / M;
+  double var = Q / M - mu * mu;
+  if (var < 0) var = 0;
+  const float muf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)eps));
+  if (rl == 0) {
+    mean[c] = muf;
+    invstd[c] = isf;
+    if (running_mean) {
+      const double unb = M > 1 ? var * ((double)M / (M - 1)) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+  }
+  const float sc = isf * gamma[c], sh = beta[c] - muf * sc;
+#pragma unroll
+  for (int i = 0; i < BN_SMALL_RPT; ++i) {
+    const int r = rl + 32 * i;
+    if (r < M) y[(long)r * C + c] = apply_act(xs[i] * sc + sh, act);
+  }
+}
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int accumulate, int M, int C, int act) {
+  __shared__ float rs[32][8], rq[32][8];
+  const int cc = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cc;
+  const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+  const float sc = is * g, sh = b - mu * sc;
+  float dz[BN_SMALL_RPT], xh[BN_SMALL_RPT];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < BN_SMALL_RPT; ++i) {
+    const int r = rl + 32 * i;
+    dz[i] = 0.f;
+    xh[i] = 0.f;
+    if (r < M) {
+      const float xr = x[(long)r * C + c];
+      xh[i] = (xr - mu) * is;
+      dz[i] = bn_dz1(dy[(long)r * C + c], xh[i], g, b, xr * sc + sh, act);
+    }
+    s += dz[i];
+    q += dz[i] * xh[i];
+  }
+  rs[rl][cc] = s;
+  rq[rl][cc] = q;
+  __syncthreads();
+  float S = 0.f, Q = 0.f;
+#pragma unroll 8
+  for (int j = 0; j < 32; ++j) { S += rs[j][cc]; Q += rq[j][cc]; }
+  if (rl == 0 && dgamma) {
+    dgamma[c] = accumulate ? dgamma[c] + Q : Q;
+    dbeta[c] = accumulate ? dbeta[c] + S : S;
+  }
+  const float invM = 1.0f / (float)M, mb = S * invM, mg = Q * invM, gi = g * is;
+#pragma unroll
+  for (int i = 0; i < BN_SMALL_RPT; ++i) {
+    const int r = rl + 32 * i;
+    if (r < M) dx[(long)r * C + c] = gi * (dz[i] - mb - xh[i] * mg);
+  }
+}
+static bool bn_small_ok(int dtype, int M, int training, const void* res, const void* mask) {
+  static const bool off = getenv("MMSA_BN_SMALL") && atoi(getenv("MMSA_BN_SMALL")) == 0;
+  return !off && dtype == MMSA_F32 && training && M <= BN_SMALL_ROWS && !res && !mask;
+}
+
 // Minimum rows a lane walks in the partial-sum kernels. 16 leaves the mid-size layers with 49-392 workgroups for 256 CUs
 // (C = 64 at 200704 rows: 392; C = 256 at 12544 rows: 98), yet 4 (4x the chunks) measured SLOWER on the whole step (19.66 vs
 // 19.46 ms): every extra chunk is another partial row for the finalize kernels, 114 latency-bound launches per step.
@@ -369,6 +468,12 @@ int bn_forward(int dtype, const void* x, const float* gamma, const float* beta, 
   if (C % 8 || M <= 0) return MMSA_ERR_ARG;
   if (!training && (!running_mean || !running_var)) return MMSA_ERR_ARG;
   if (relu_mask && act != MMSA_ACT_RELU) return MMSA_ERR_ARG;
+  if (bn_small_ok(dtype, M, training, res, relu_mask)) {
+    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C / 8), dim3(256), 0, st, (const float*)x, gamma, beta, running_mean,
+                       running_var, mean, invstd, (float*)y, M, C, eps, momentum, act);
+    MMSA_CHECK_LAUNCH();
+    return MMSA_OK;
+  }
   if (dtype == MMSA_BF16)
     return bn_forward_t<bf16>((const bf16*)x, gamma, beta, running_mean, running_var, mean, invstd, (const bf16*)res,
                               (bf16*)y, ws, M, C, eps, momentum, act, training, st, relu_mask);
@@ -400,6 +505,13 @@ int bn_backward(int dtype, const void* dy, const void* x, const void* y, const f
                 float* ws, int M, int C, int act, int training, hipStream_t st, const unsigned char* relu_mask) {
   if (C % 8 || M <= 0) return MMSA_ERR_ARG;
   if (relu_mask && act != MMSA_ACT_RELU) return MMSA_ERR_ARG;
+  // (a saved output with ReLU means the forward may have added a residual: the streamed kernels read the sign from it)
+  if (bn_small_ok(dtype, M, training, dres, relu_mask) && !(act == MMSA_ACT_RELU && y)) {
+    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C / 8), dim3(256), 0, st, (const float*)dy, (const float*)x, mean, invstd,
+                       gamma, beta, (float*)dx, dgamma, dbeta, accumulate, M, C, act);
+    MMSA_CHECK_LAUNCH();
+    return MMSA_OK;
+  }
   if (dtype == MMSA_BF16)
     return bn_backward_t<bf16>((const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, gamma, beta, (bf16*)dx,
                                (bf16*)dres, dgamma, dbeta, accumulate, ws, M, C, act, training, st, relu_mask);

@@ -345,9 +345,7 @@ static int mmf_fwd(const HCtx& h, const HeadLayout& L, HeadWs& w, const float* c
   const Eng& e = h.e;
   // L2-normalise every modality into the token sequence seqn[b][m][:]
   for (int m = 0; m < M; ++m) {
-    // write rows with stride M*E by normalising into a temp then a strided copy
-    RET_IF(l2norm_fwd(in[m], w.dseq, w.nrm + (long)m * B, B, E, 1e-12f, e.st));
-    RET_IF(ew2d(EW_COPY, w.dseq, E, nullptr, 0, w.seqn + (long)m * E, (long)M * E, B, E, e.st));
+    RET_IF(l2norm_fwd_ld(in[m], w.seqn + (long)m * E, (long)M * E, w.nrm + (long)m * B, B, E, 1e-12f, e.st));
   }
   RET_IF(e.linear_fwd(w.seqn, E, h.P(L.mha.inw), h.P(L.mha.inb), w.qkv, 3 * E, B * M, 3 * E, E));
   RET_IF(mha_core_fwd(w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.ctx, E, w.probs, B, M, M, E, h.c.heads, e.st));
@@ -374,10 +372,9 @@ static int mmf_bwd(const HCtx& h, const HeadLayout& L, HeadWs& w, const float* c
   }
   RET_IF(e.linear_dgrad(w.dqkv, 3 * E, h.P(L.mha.inw), w.dseq, E, B * M, 3 * E, E));
   for (int m = 0; m < M; ++m) {
-    // gather modality m's rows (stride M*E) and run the L2-norm backward into din[m]
-    RET_IF(ew2d(EW_COPY, w.dseq + (long)m * E, (long)M * E, nullptr, 0, w.dattn, E, B, E, e.st));
-    RET_IF(ew2d(EW_COPY, w.seqn + (long)m * E, (long)M * E, nullptr, 0, w.dctx1, E, B, E, e.st));
-    RET_IF(l2norm_bwd(w.dattn, w.dctx1, w.nrm + (long)m * B, din[m], B, E, 1e-12f, 0, e.st));
+    // modality m's rows sit at stride M*E in the token sequence
+    RET_IF(l2norm_bwd_ld(w.dseq + (long)m * E, w.seqn + (long)m * E, (long)M * E, w.nrm + (long)m * B, din[m], B, E, 1e-12f, 0,
+                         e.st));
   }
   return MMSA_OK;
 }
@@ -387,7 +384,7 @@ static int mmf_bwd(const HCtx& h, const HeadLayout& L, HeadWs& w, const float* c
 static int wh_fwd(const HCtx& h, const HeadLayout& L, HeadWs& w, const float* const* in, float* const* out) {
   const int B = h.c.batch, E = h.c.embed;
   const Eng& e = h.e;
-  for (int i = 0; i < 3; ++i) RET_IF(ew2d(EW_COPY, in[i], E, nullptr, 0, w.cat3 + (long)i * E, 3 * E, B, E, e.st));
+  RET_IF(cat3_fwd(in[0], in[1], in[2], w.cat3, B, E, e.st));
   RET_IF(h.lin_fwd(L.aw0, w.cat3, 3 * E, w.awact, 64, B, MMSA_ACT_GELU, w.awpre));
   RET_IF(h.lin_fwd(L.aw2, w.awact, 64, w.wl, 3, B));
   RET_IF(weighted_concat_fwd(w.wl, in[0], in[3], in[4], w.wsm, w.wcat, B, E, e.st));
@@ -439,9 +436,7 @@ static int wh_bwd(const HCtx& h, const HeadLayout& L, HeadWs& w, const float* co
   // attention_weights MLP: Linear(3E,64) GELU Linear(64,3)
   RET_IF(h.lin_bwd(L.aw2, w.dwl, 3, w.awact, 64, w.dawact, 64, B, w.awpre, 64));  // * gelu'(pre) fused
   RET_IF(h.lin_bwd(L.aw0, w.dawact, 64, w.cat3, 3 * E, w.dcat3, 3 * E, B));
-  RET_IF(ew2d(EW_ADD, w.dcat3, 3 * E, w.df[0], E, din[0], E, B, E, e.st));
-  RET_IF(ew2d(EW_COPY, w.dcat3 + E, 3 * E, nullptr, 0, din[1], E, B, E, e.st));
-  return ew2d(EW_COPY, w.dcat3 + 2 * E, 3 * E, nullptr, 0, din[2], E, B, E, e.st);
+  return cat3_bwd(w.dcat3, w.df[0], din[0], din[1], din[2], B, E, e.st);
 }
 
 // ------------------------------------------------------------------------------------------------ kind 3: Classifier

@@ -14,42 +14,52 @@
 // ------------------------------------------------------------------------------------------------ L2 normalise
 // y = x / max(||x||, eps)   (F.normalize, MultimodalModel.py:388-390); one wave per row
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                         float* __restrict__ nrm, int M, int E, float eps) {
+                                                         float* __restrict__ nrm, int M, int E, float eps, long ldy) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   float s = 0.f;
   for (int e = lane; e < E; e += 64) { const float v = x[(long)row * E + e]; s += v * v; }
   const float n = fmaxf(sqrtf(wave_sum(s)), eps);
   if (lane == 0) nrm[row] = n;
-  for (int e = lane; e < E; e += 64) y[(long)row * E + e] = x[(long)row * E + e] / n;
+  for (int e = lane; e < E; e += 64) y[(long)row * ldy + e] = x[(long)row * E + e] / n;
 }
 // dx = (dy - y (y . dy)) / n   (for ||x|| > eps; below eps the map is linear: dx = dy / eps)
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                          const float* __restrict__ nrm, float* __restrict__ dx, int M, int E,
-                                                         float eps, int accumulate) {
+                                                         float eps, int accumulate, long ldin) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   float s = 0.f;
-  for (int e = lane; e < E; e += 64) s += y[(long)row * E + e] * dy[(long)row * E + e];
+  for (int e = lane; e < E; e += 64) s += y[(long)row * ldin + e] * dy[(long)row * ldin + e];
   s = wave_sum(s);
   const float n = nrm[row];
   if (n <= eps) s = 0.f;
   for (int e = lane; e < E; e += 64) {
-    const float g = (dy[(long)row * E + e] - y[(long)row * E + e] * s) / n;
+    const float g = (dy[(long)row * ldin + e] - y[(long)row * ldin + e] * s) / n;
     float* d = dx + (long)row * E + e;
     *d = accumulate ? *d + g : g;
   }
 }
-int l2norm_fwd(const float* x, float* y, float* nrm, int M, int E, float eps, hipStream_t st) {
-  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, y, nrm, M, E, eps);
+// ldy / ldin: row stride of the normalised rows (and of their gradient) - the A2 head keeps them interleaved as tokens of
+// one sequence [B][modalities][E]; 0 means dense (E)
+int l2norm_fwd_ld(const float* x, float* y, long ldy, float* nrm, int M, int E, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, y, nrm, M, E, eps, ldy ? ldy : (long)E);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
-int l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int M, int E, float eps, int accumulate,
-               hipStream_t st) {
-  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, dy, y, nrm, dx, M, E, eps, accumulate);
+int l2norm_bwd_ld(const float* dy, const float* y, long ldin, const float* nrm, float* dx, int M, int E, float eps,
+                  int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, dy, y, nrm, dx, M, E, eps, accumulate,
+                     ldin ? ldin : (long)E);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
+}
+int l2norm_fwd(const float* x, float* y, float* nrm, int M, int E, float eps, hipStream_t st) {
+  return l2norm_fwd_ld(x, y, 0, nrm, M, E, eps, st);
+}
+int l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int M, int E, float eps, int accumulate,
+               hipStream_t st) {
+  return l2norm_bwd_ld(dy, y, 0, nrm, dx, M, E, eps, accumulate, st);
 }
 
 // ------------------------------------------------------------------------------------------------ MHA core
@@ -372,6 +382,44 @@ __global__ void ew2d_kernel(const float* __restrict__ a, long lda, const float* 
     out[(long)r * ldo + c] = v;
   }
 }
+// out[r] = [a[r] | b[r] | c[r]] and its backward da = dcat[:, :E] + add0, db = dcat[:, E:2E], dc = dcat[:, 2E:]
+// (the attention-weights MLP input of the weighted head, MultimodalModel.py:264)
+__global__ void cat3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                            float* __restrict__ out, int rows, int E) {
+  const long total = (long)rows * 3 * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / (3 * E);
+    const int j = (int)(i - r * 3 * E), part = j / E, e = j - part * E;
+    const float* src = part == 0 ? a : (part == 1 ? b : c);
+    out[i] = src[r * E + e];
+  }
+}
+__global__ void cat3_bwd_kernel(const float* __restrict__ dcat, const float* __restrict__ add0, float* __restrict__ da,
+                                float* __restrict__ db, float* __restrict__ dc, int rows, int E) {
+  const long total = (long)rows * 3 * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / (3 * E);
+    const int j = (int)(i - r * 3 * E), part = j / E, e = j - part * E;
+    const float v = dcat[i];
+    if (part == 0) da[r * E + e] = v + add0[r * E + e];
+    else if (part == 1) db[r * E + e] = v;
+    else dc[r * E + e] = v;
+  }
+}
+int cat3_fwd(const float* a, const float* b, const float* c, float* out, int rows, int E, hipStream_t st) {
+  const long total = (long)rows * 3 * E;
+  hipLaunchKernelGGL(cat3_kernel, dim3((int)min((total + 255) / 256, 2048L)), dim3(256), 0, st, a, b, c, out, rows, E);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+int cat3_bwd(const float* dcat, const float* add0, float* da, float* db, float* dc, int rows, int E, hipStream_t st) {
+  const long total = (long)rows * 3 * E;
+  hipLaunchKernelGGL(cat3_bwd_kernel, dim3((int)min((total + 255) / 256, 2048L)), dim3(256), 0, st, dcat, add0, da, db, dc,
+                     rows, E);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
 int ew2d(int op, const float* a, long lda, const float* b, long ldb, float* out, long ldo, int rows, int cols, hipStream_t st) {
   const long total = (long)rows * cols;
   hipLaunchKernelGGL(ew2d_kernel, dim3((int)min((total + 255) / 256, 2048L)), dim3(256), 0, st, a, lda, b, ldb, out, ldo,

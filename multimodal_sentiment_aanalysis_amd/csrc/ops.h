@@ -72,6 +72,11 @@ int unpad_rows(const float* src, float* dst, int rows, int cols_src, int cols_ds
 
 // headops.hip (fp32)
 int l2norm_fwd(const float* x, float* y, float* nrm, int M, int E, float eps, hipStream_t st);
+int l2norm_fwd_ld(const float* x, float* y, long ldy, float* nrm, int M, int E, float eps, hipStream_t st);
+int l2norm_bwd_ld(const float* dy, const float* y, long ldin, const float* nrm, float* dx, int M, int E, float eps,
+                  int accumulate, hipStream_t st);
+int cat3_fwd(const float* a, const float* b, const float* c, float* out, int rows, int E, hipStream_t st);
+int cat3_bwd(const float* dcat, const float* add0, float* da, float* db, float* dc, int rows, int E, hipStream_t st);
 int l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int M, int E, float eps, int accumulate,
                hipStream_t st);
 int mha_core_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* ctx, long ldc,

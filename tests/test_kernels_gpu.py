@@ -307,6 +307,7 @@ def test_attention(dev, impl, dtype, B, S, heads, masked):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,C,act,use_res", [(512, 64, ACT_RELU, False), (128, 64, ACT_RELU, True), (2048, 256, ACT_RELU, True),
                                              (32, 512, ACT_NONE, False), (8, 128, ACT_RELU, False), (16, 256, ACT_GELU, False),
+                                             (64, 256, ACT_GELU, False), (200, 128, ACT_NONE, False), (256, 64, ACT_GELU, False),
                                              (1000, 192, ACT_RELU, True)])
 def test_batchnorm(dev, dtype, M, C, act, use_res):
     x = rnd((M, C), dtype, dev, 1, 2.0)
