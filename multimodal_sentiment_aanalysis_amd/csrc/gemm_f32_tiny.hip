@@ -1,0 +1,111 @@
+// Latency-oriented exact-fp32 GEMM for the fusion head's batch-row problems (M = 64-128 rows, N, K <= 768; A1-A5 of
+// MultimodalModel.py:108-149, 171-225, 388-451).
+//
+// These launches are not throughput problems: 64 x 256 x 768 is 25 MFLOP.  The VALU kernel (gemm_simt.hip) walks K in
+// 16-wide LDS-staged steps, ~0.15 us of latency each, so it needs a K split over workgroups plus a reducer launch to get
+// under 10 us.  Here one WAVE owns a 16 x 16 output tile on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate),
+// reads its operands straight from global memory (L2-resident at these sizes) 64 k-values at a time with the next chunk's
+// loads in flight under the current chunk's 16 MFMAs, and the 4 waves of a workgroup split K between them; their partial
+// tiles are added in wave order through LDS (fixed summation order: bitwise reproducible) and the usual fused epilogue is
+// applied.  One launch, no workspace.
+//
+// Operand fragment of the 16x16x4 MFMA: lane (r = lane % 16, g = lane / 16) supplies A[r][k_g] and B[k_g][r].  A dot
+// product does not care which real k sits in which (step, g) slot as long as A and B agree, so lane (r, g) takes the 16
+// CONTIGUOUS k-values g*16 .. g*16+15 of its chunk (four 16-byte loads when k is the contiguous dimension) and step s uses
+// element s.
+#include "gemm_epilogue.h"
+
+#define TY_CHUNK 64
+
+template <bool KM>
+__device__ __forceinline__ void tiny_load(const float* __restrict__ X, long ld, int x, int X_n, int kb, int K, float* v) {
+  // X_n: extent of the non-contracted dimension; x: this lane's row / column in it; kb: first of the lane's 16 k-values
+  if constexpr (!KM) {
+    const float* row = X + (long)x * ld + kb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (x < X_n && kb + 4 * q < K) t = *(const f32x4*)(row + 4 * q);  // K % 4 == 0: a float4 never straddles the end
+      v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = (x < X_n && kb + s < K) ? X[(long)(kb + s) * ld + x] : 0.f;
+  }
+}
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_f32_tiny_kernel(GemmParams p, int KS, int tiles_n, int ntiles) {
+  __shared__ float img[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int tpb = 4 / KS;
+  const int tib = wave / KS, ks = wave - tib * KS;
+  const int tile = blockIdx.x * tpb + tib;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (tile < ntiles) {
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m = tm * 16 + r, n = tn * 16 + r;
+    const float* A = (const float*)p.A;
+    const float* B = (const float*)p.B;
+    const int nch = (p.K + TY_CHUNK - 1) / TY_CHUNK;
+    float a0[16], b0[16], a1[16], b1[16];
+    int c = ks;
+    if (c < nch) {
+      tiny_load<A_KM>(A, p.lda, m, p.M, c * TY_CHUNK + g * 16, p.K, a0);
+      tiny_load<B_KM>(B, p.ldb, n, p.N, c * TY_CHUNK + g * 16, p.K, b0);
+    }
+    for (; c < nch; c += KS) {
+      const int cn = c + KS;
+      if (cn < nch) {
+        tiny_load<A_KM>(A, p.lda, m, p.M, cn * TY_CHUNK + g * 16, p.K, a1);
+        tiny_load<B_KM>(B, p.ldb, n, p.N, cn * TY_CHUNK + g * 16, p.K, b1);
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], acc, 0, 0, 0);
+      if (cn < nch) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { a0[s] = a1[s]; b0[s] = b1[s]; }
+      }
+    }
+  }
+  // C fragment: acc[j] = C[4g + j][r]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) img[wave][(4 * g + j) * 16 + r] = acc[j];
+  __syncthreads();
+  const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+  for (int t = 0; t < tpb; ++t) {
+    const int tl = blockIdx.x * tpb + t;
+    if (tl >= ntiles) break;
+    const int tm = tl / tiles_n, tn = tl - tm * tiles_n;
+    const int m = tm * 16 + row, n = tn * 16 + col;
+    float v = img[t * KS][threadIdx.x];
+    for (int k = 1; k < KS; ++k) v += img[t * KS + k][threadIdx.x];
+    if (m < p.M && n < p.N) gemm_epilogue1<float>(p, m, n, v);
+  }
+}
+
+bool gemm_f32_tiny_eligible(const GemmParams& p) {
+  static const bool off = [] { const char* v = getenv("MMSA_F32_TINY"); return v && atoi(v) == 0; }();
+  if (off || p.gather != 0 || p.c_gw > 0 || p.M <= 0 || p.N <= 0 || p.K <= 0) return false;
+  if ((double)p.M * p.N * p.K > (double)(1 << 25)) return false;  // beyond: operand re-reads (no LDS sharing) start to cost
+  if (!p.a_kmajor && ((p.K & 3) || (p.lda & 3) || ((uintptr_t)p.A & 15))) return false;
+  if (!p.b_kmajor && ((p.K & 3) || (p.ldb & 3) || ((uintptr_t)p.B & 15))) return false;
+  return true;
+}
+
+int gemm_f32_tiny_launch(const GemmParams& pin, hipStream_t st) {
+  GemmParams p = pin;
+  p.split_k = 1;  // the waves of a workgroup split K; no slabs, no reducer
+  p.ws = nullptr;
+  const int tiles_m = cdiv(p.M, 16), tiles_n = cdiv(p.N, 16), ntiles = tiles_m * tiles_n;
+  const int KS = p.K >= 256 ? 4 : (p.K >= 128 ? 2 : 1);
+  const dim3 grid(cdiv(ntiles, 4 / KS));
+#define TINY_CASE(AK, BK) \
+  hipLaunchKernelGGL((gemm_f32_tiny_kernel<AK, BK>), grid, dim3(256), 0, st, p, KS, tiles_n, ntiles)
+  if (p.a_kmajor) { if (p.b_kmajor) TINY_CASE(true, true); else TINY_CASE(true, false); }
+  else            { if (p.b_kmajor) TINY_CASE(false, true); else TINY_CASE(false, false); }
+#undef TINY_CASE
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}

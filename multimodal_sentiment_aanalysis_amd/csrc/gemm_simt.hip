@@ -169,6 +169,7 @@ static int simt_launch(const GemmParams& pin, hipStream_t st) {
 
 int gemm_f32_valu_launch(const GemmParams& p, hipStream_t st) { return simt_launch<float>(p, st); }
 int gemm_f32_launch(const GemmParams& pin, hipStream_t st) {
+  if (gemm_f32_tiny_eligible(pin)) return gemm_f32_tiny_launch(pin, st);
   if (!gemm_f32_mfma_eligible(pin)) return simt_launch<float>(pin, st);
   GemmParams p = pin;
   const int slot = gemm_prof_open(p, st);
