@@ -4,10 +4,9 @@
 // These launches are not throughput problems: 64 x 256 x 768 is 25 MFLOP.  The VALU kernel (gemm_simt.hip) walks K in
 // 16-wide LDS-staged steps, ~0.15 us of latency each, so it needs a K split over workgroups plus a reducer launch to get
 // under 10 us.  Here one WAVE owns a 16 x 16 output tile on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate),
-// reads its operands straight from global memory (L2-resident at these sizes) 64 k-values at a time with the next chunk's
-// loads in flight under the current chunk's 16 MFMAs, and the 4 waves of a workgroup split K between them; their partial
-// tiles are added in wave order through LDS (fixed summation order: bitwise reproducible) and the usual fused epilogue is
-// applied.  One launch, no workspace.
+// reads its operands straight from global memory 64 k-values at a time, up to three such chunks in flight at once, and
+// the 4 waves of a workgroup split K between them; their partial tiles are added in wave order through LDS (fixed
+// summation order: bitwise reproducible) and the usual fused epilogue is applied.  One launch, no workspace.
 //
 // Operand fragment of the 16x16x4 MFMA: lane (r = lane % 16, g = lane / 16) supplies A[r][k_g] and B[k_g][r].  A dot
 // product does not care which real k sits in which (step, g) slot as long as A and B agree, so lane (r, g) takes the 16
@@ -49,23 +48,23 @@ __global__ __launch_bounds__(256) void gemm_f32_tiny_kernel(GemmParams p, int KS
     const float* A = (const float*)p.A;
     const float* B = (const float*)p.B;
     const int nch = (p.K + TY_CHUNK - 1) / TY_CHUNK;
-    float a0[16], b0[16], a1[16], b1[16];
-    int c = ks;
-    if (c < nch) {
-      tiny_load<A_KM>(A, p.lda, m, p.M, c * TY_CHUNK + g * 16, p.K, a0);
-      tiny_load<B_KM>(B, p.ldb, n, p.N, c * TY_CHUNK + g * 16, p.K, b0);
-    }
-    for (; c < nch; c += KS) {
-      const int cn = c + KS;
-      if (cn < nch) {
-        tiny_load<A_KM>(A, p.lda, m, p.M, cn * TY_CHUNK + g * 16, p.K, a1);
-        tiny_load<B_KM>(B, p.ldb, n, p.N, cn * TY_CHUNK + g * 16, p.K, b1);
+    // up to three chunks per wave in flight at once (K <= 768 with the 4-way split: ONE memory round trip per launch)
+    float a[3][16], b[3][16];
+    for (int c = ks; c < nch; c += 3 * KS) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int cu = c + u * KS;
+        if (cu < nch) {
+          tiny_load<A_KM>(A, p.lda, m, p.M, cu * TY_CHUNK + g * 16, p.K, a[u]);
+          tiny_load<B_KM>(B, p.ldb, n, p.N, cu * TY_CHUNK + g * 16, p.K, b[u]);
+        }
       }
 #pragma unroll
-      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], acc, 0, 0, 0);
-      if (cn < nch) {
+      for (int u = 0; u < 3; ++u) {
+        if (c + u * KS < nch) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) { a0[s] = a1[s]; b0[s] = b1[s]; }
+          for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b[u][s], acc, 0, 0, 0);
+        }
       }
     }
   }
