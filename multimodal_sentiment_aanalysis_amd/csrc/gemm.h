@@ -103,6 +103,9 @@ int gemm_f32_valu_launch(const GemmParams& p, hipStream_t st);  // the VALU-fma 
 // one-launch fp32-MFMA kernel for batch-row problems (gemm_f32_tiny.hip); gemm_f32_launch routes eligible problems to it
 bool gemm_f32_tiny_eligible(const GemmParams& p);
 int gemm_f32_tiny_launch(const GemmParams& p, hipStream_t st);
+// the same kernel on bf16 operands (<= 128 rows: BERT pooler, the two projections into the fusion width)
+bool gemm_bf16_tiny_eligible(const GemmParams& p);
+int gemm_bf16_tiny_launch(const GemmParams& p, hipStream_t st);
 int gemm_f32_mfma_launch(const GemmParams& p, hipStream_t st);
 // roofline record of one matrix-core launch made outside gemm_mfma.hip: open returns a slot (or -1: not recording) and sets
 // p.stamp / records the start event; close records the end event

@@ -16,25 +16,34 @@
 
 #define TY_CHUNK 64
 
-template <bool KM>
-__device__ __forceinline__ void tiny_load(const float* __restrict__ X, long ld, int x, int X_n, int kb, int K, float* v) {
+template <bool KM, typename T>
+__device__ __forceinline__ void tiny_load(const T* __restrict__ X, long ld, int x, int X_n, int kb, int K, float* v) {
   // X_n: extent of the non-contracted dimension; x: this lane's row / column in it; kb: first of the lane's 16 k-values
-  if constexpr (!KM) {
-    const float* row = X + (long)x * ld + kb;
+  if constexpr (!KM && sizeof(T) == 4) {
+    const float* row = (const float*)X + (long)x * ld + kb;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
       if (x < X_n && kb + 4 * q < K) t = *(const f32x4*)(row + 4 * q);  // K % 4 == 0: a float4 never straddles the end
       v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
     }
+  } else if constexpr (!KM) {  // bf16 operands (the encoders' batch-row Linears): widened, same exact-product MFMA
+    const bf16* row = (const bf16*)X + (long)x * ld + kb;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      bf16x8 t = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (x < X_n && kb + 8 * q < K) t = *(const bf16x8*)(row + 8 * q);  // K % 8 == 0
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[8 * q + e] = (float)t[e];
+    }
   } else {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) v[s] = (x < X_n && kb + s < K) ? X[(long)(kb + s) * ld + x] : 0.f;
+    for (int s = 0; s < 16; ++s) v[s] = (x < X_n && kb + s < K) ? to_f32<T>(X[(long)(kb + s) * ld + x]) : 0.f;
   }
 }
 
-template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(256) void gemm_f32_tiny_kernel(GemmParams p, int KS, int tiles_n, int ntiles) {
+template <typename T, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmParams p, int KS, int tiles_n, int ntiles) {
   __shared__ float img[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -45,8 +54,8 @@ __global__ __launch_bounds__(256) void gemm_f32_tiny_kernel(GemmParams p, int KS
   if (tile < ntiles) {
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m = tm * 16 + r, n = tn * 16 + r;
-    const float* A = (const float*)p.A;
-    const float* B = (const float*)p.B;
+    const T* A = (const T*)p.A;
+    const T* B = (const T*)p.B;
     const int nch = (p.K + TY_CHUNK - 1) / TY_CHUNK;
     // up to three chunks per wave in flight at once (K <= 768 with the 4-way split: ONE memory round trip per launch)
     float a[3][16], b[3][16];
@@ -80,20 +89,30 @@ __global__ __launch_bounds__(256) void gemm_f32_tiny_kernel(GemmParams p, int KS
     const int m = tm * 16 + row, n = tn * 16 + col;
     float v = img[t * KS][threadIdx.x];
     for (int k = 1; k < KS; ++k) v += img[t * KS + k][threadIdx.x];
-    if (m < p.M && n < p.N) gemm_epilogue1<float>(p, m, n, v);
+    if (m < p.M && n < p.N) gemm_epilogue1<T>(p, m, n, v);
   }
 }
 
-bool gemm_f32_tiny_eligible(const GemmParams& p) {
+template <typename T>
+static bool tiny_eligible(const GemmParams& p) {
   static const bool off = [] { const char* v = getenv("MMSA_F32_TINY"); return v && atoi(v) == 0; }();
-  if (off || p.gather != 0 || p.c_gw > 0 || p.M <= 0 || p.N <= 0 || p.K <= 0) return false;
-  if ((double)p.M * p.N * p.K > (double)(1 << 25)) return false;  // beyond: operand re-reads (no LDS sharing) start to cost
-  if (!p.a_kmajor && ((p.K & 3) || (p.lda & 3) || ((uintptr_t)p.A & 15))) return false;
-  if (!p.b_kmajor && ((p.K & 3) || (p.ldb & 3) || ((uintptr_t)p.B & 15))) return false;
+  if (off || p.gather != 0 || p.c_gw > 0 || p.M <= 0 || p.N <= 0 || p.K <= 0 || p.scale_a) return false;
+  // beyond: operand re-reads (no LDS sharing between the tiles of a workgroup) start to cost.  bf16: one notch higher so
+  // that the BERT pooler (64 x 768 x 768) is in
+  if ((double)p.M * p.N * p.K > (double)(1 << (sizeof(T) == 4 ? 25 : 26))) return false;
+  constexpr int V = 16 / sizeof(T);  // elements per 16-byte load
+  if (!p.a_kmajor && ((p.K % V) || (p.lda % V) || ((uintptr_t)p.A & 15))) return false;
+  if (!p.b_kmajor && ((p.K % V) || (p.ldb % V) || ((uintptr_t)p.B & 15))) return false;
   return true;
 }
+bool gemm_f32_tiny_eligible(const GemmParams& p) { return tiny_eligible<float>(p); }
+bool gemm_bf16_tiny_eligible(const GemmParams& p) {
+  static const bool off = [] { const char* v = getenv("MMSA_BF16_TINY"); return v && atoi(v) == 0; }();
+  return !off && p.M <= 128 && tiny_eligible<bf16>(p);
+}
 
-int gemm_f32_tiny_launch(const GemmParams& pin, hipStream_t st) {
+template <typename T>
+static int tiny_launch(const GemmParams& pin, hipStream_t st) {
   GemmParams p = pin;
   p.split_k = 1;  // the waves of a workgroup split K; no slabs, no reducer
   p.ws = nullptr;
@@ -101,10 +120,12 @@ int gemm_f32_tiny_launch(const GemmParams& pin, hipStream_t st) {
   const int KS = p.K >= 256 ? 4 : (p.K >= 128 ? 2 : 1);
   const dim3 grid(cdiv(ntiles, 4 / KS));
 #define TINY_CASE(AK, BK) \
-  hipLaunchKernelGGL((gemm_f32_tiny_kernel<AK, BK>), grid, dim3(256), 0, st, p, KS, tiles_n, ntiles)
+  hipLaunchKernelGGL((gemm_tiny_kernel<T, AK, BK>), grid, dim3(256), 0, st, p, KS, tiles_n, ntiles)
   if (p.a_kmajor) { if (p.b_kmajor) TINY_CASE(true, true); else TINY_CASE(true, false); }
   else            { if (p.b_kmajor) TINY_CASE(false, true); else TINY_CASE(false, false); }
 #undef TINY_CASE
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
+int gemm_f32_tiny_launch(const GemmParams& p, hipStream_t st) { return tiny_launch<float>(p, st); }
+int gemm_bf16_tiny_launch(const GemmParams& p, hipStream_t st) { return tiny_launch<bf16>(p, st); }

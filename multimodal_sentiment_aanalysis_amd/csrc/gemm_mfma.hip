@@ -488,6 +488,8 @@ void gemm_prof_close(int slot, hipStream_t st) {
 }
 
 int gemm_bf16_launch(const GemmParams& pin, hipStream_t st) {
+  // batch-row problems: latency, not throughput (gemm_f32_tiny.hip); not part of the MFMA roofline record set
+  if (gemm_bf16_tiny_eligible(pin)) return gemm_bf16_tiny_launch(pin, st);
   if (!g_prof_on || g_prof_used >= g_prof.size() || !prof_take()) return gemm_bf16_launch_inner(pin, st);
   ProfRec& r = g_prof[g_prof_used];
   r.flop = 2.0 * pin.M * pin.N * (double)pin.K;

@@ -126,11 +126,14 @@ def test_resnet_engine(dev, precision, pol, tol_f, tol_g, rcfg, B, HW):
     net.train()
     out = net(image.to(dev))
     assert rel_err(out, ref) < tol_f, f"resnet feat rel err {rel_err(out, ref)}"
-    # running statistics follow torch's update rule (momentum 0.1, unbiased variance)
+    # running statistics follow torch's update rule (momentum 0.1, unbiased variance). Full depth: the same amplification
+    # as tol_f above (variance of 8 samples in the last stage: 1.5e-4 with the batch-row GEMM kernel, 0.9e-4 with the VALU
+    # one - two fp32 summation orders, both within rounding of the fp64 product)
     post = cpu_state(net)
+    tol_s = (4e-4 if sum(rcfg["blocks"]) > 8 else 1e-4) if precision == "fp32" else 3e-2
     for k in sd_ref:
         if k.endswith("running_mean") or k.endswith("running_var"):
-            assert rel_err(post[k], sd_ref[k]) < (1e-4 if precision == "fp32" else 3e-2), k
+            assert rel_err(post[k], sd_ref[k]) < tol_s, k
         if k.endswith("num_batches_tracked"):
             assert int(post[k]) == 1
     (out * wgt.to(dev)).sum().backward()
