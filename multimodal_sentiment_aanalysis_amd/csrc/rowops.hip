@@ -6,7 +6,8 @@
 #include "gemm_epilogue.h"  // Vec4
 #include "ops.h"
 
-// NCH = per-lane 4-element chunks (template): 1 -> H <= 256, 4 -> H <= 1024, 8 -> H <= 2048
+// NCH = per-lane 4-element chunks (template): 1 -> H <= 256, 3 -> H <= 768 (BERT-base: no dead fourth chunk), 4 -> H <= 1024,
+// 8 -> H <= 2048
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 template <typename T, int NCH>
@@ -248,6 +249,7 @@ int partial_finalize(const float* part, int nblk, long stride, int n, float* out
 #define LN_DISPATCH(KERNEL, T, H, ...)                                                           \
   do {                                                                                           \
     if ((H) <= 256) hipLaunchKernelGGL((KERNEL<T, 1>), __VA_ARGS__);                              \
+    else if ((H) <= 768) hipLaunchKernelGGL((KERNEL<T, 3>), __VA_ARGS__);                         \
     else if ((H) <= 1024) hipLaunchKernelGGL((KERNEL<T, 4>), __VA_ARGS__);                        \
     else hipLaunchKernelGGL((KERNEL<T, 8>), __VA_ARGS__);                                         \
   } while (0)
