@@ -114,6 +114,42 @@ def test_gemm_f32_n3(dev):
     assert_close(C, A.cpu().double() @ B.cpu().double().T + bias.cpu().double(), torch.float32, "N=3")
 
 
+@pytest.mark.parametrize("dtype,impl", [(torch.float32, GEMM_F32_SIMT), (torch.bfloat16, GEMM_BF16_MFMA)])
+@pytest.mark.parametrize("M,N,Kd,lay", [(64, 256, 256, "NT"), (64, 256, 768, "NT"), (128, 768, 256, "NT"), (64, 3, 128, "NT"),
+                                        (64, 768, 768, "NT"), (50, 72, 200, "NT"), (64, 256, 2048, "NT"), (64, 768, 256, "NN"),
+                                        (128, 256, 768, "NN"), (64, 128, 8, "NN"), (256, 768, 64, "TN"), (768, 256, 128, "TN"),
+                                        (8, 128, 64, "TN"), (128, 256, 192, "TK")])
+def test_gemm_batch_rows(dev, dtype, impl, M, N, Kd, lay):
+    """Batch-row problems (fusion head, pooler, projections) take the one-launch 16x16-per-wave MFMA kernel
+    (gemm_f32_tiny.hip) through the ordinary entry point: every operand layout, K tails inside a 64-chunk, partial tiles,
+    bias + accumulate epilogues; checked against the float64 product at storage resolution."""
+    f32 = torch.float32
+    if lay == "NT":
+        A, B = rnd((M, Kd), dtype, dev, 1), rnd((N, Kd), dtype, dev, 2)
+        kw, ref = dict(lda=Kd, ldb=Kd), A.cpu().double() @ B.cpu().double().T
+    elif lay == "NN":
+        A, B = rnd((M, Kd), dtype, dev, 1), rnd((Kd, N), dtype, dev, 2)
+        kw, ref = dict(lda=Kd, ldb=N, b_kmajor=1), A.cpu().double() @ B.cpu().double()
+    elif lay == "TN":
+        A, B = rnd((Kd, M), dtype, dev, 1), rnd((Kd, N), dtype, dev, 2)
+        kw, ref = dict(lda=M, ldb=N, a_kmajor=1, b_kmajor=1), A.cpu().double().T @ B.cpu().double()
+    else:
+        A, B = rnd((Kd, M), dtype, dev, 1), rnd((N, Kd), dtype, dev, 2)
+        kw, ref = dict(lda=M, ldb=Kd, a_kmajor=1), A.cpu().double().T @ B.cpu().double().T
+    bias = rnd((N,), f32, dev, 3)
+    if dtype == torch.bfloat16 and N % 4:
+        pytest.skip("bf16 launchers take N % 4 == 0")
+    C = torch.empty(M, N, dtype=dtype, device=dev)
+    K.gemm(A, B, C, M, N, Kd, kw["lda"], kw["ldb"], N, a_kmajor=kw.get("a_kmajor", 0), b_kmajor=kw.get("b_kmajor", 0),
+           bias=bias, impl=impl)
+    assert_close(C, ref + bias.cpu().double(), dtype, f"{lay} bias", k=Kd)
+    C0 = rnd((M, N), f32, dev, 4)
+    Cf = C0.clone()
+    K.gemm(A, B, Cf, M, N, Kd, kw["lda"], kw["ldb"], N, a_kmajor=kw.get("a_kmajor", 0), b_kmajor=kw.get("b_kmajor", 0),
+           out_f32=1, accumulate=1, impl=impl)
+    assert_close(Cf, C0.cpu().double() + ref, f32 if dtype == f32 else torch.bfloat16, f"{lay} accumulate", k=Kd)
+
+
 @pytest.mark.parametrize("case", ["nt", "nn", "tn_split", "tn_kc", "edge", "epilogue"])
 def test_gemm_f32_mfma_matches_valu_bitwise(dev, case):
     """The exact-fp32 matrix-core kernel (v_mfma_f32_32x32x2_f32, gemm_f32_mfma.hip) against the VALU-fma kernel: the MFMA
