@@ -17,6 +17,7 @@ static GemmParams to_params(const mmsa_gemm_desc* d) {
   p.b_tap_stride = d->b_tap_stride; p.b_tap_stride_y = 0;
   p.c2_gelu_grad = 0; p.mul_is_factor = 0;
   p.scale_a = p.scale_b = nullptr;
+  p.b_ones = 0;
   const mmsa_conv_geom& s = d->geom;
   ConvGeom& g = p.g;
   g.SH = s.SH; g.SW = s.SW; g.GH = s.GH; g.GW = s.GW; g.KH = s.KH; g.KW = s.KW;

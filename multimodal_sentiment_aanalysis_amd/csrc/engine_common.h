@@ -248,4 +248,40 @@ struct Eng {
   int bias_grad(const void* dy, long lddy, float* db, int M, int N, int accumulate) const {
     return colsum(dtype, dy, lddy, db, accumulate, col_ws, M, N, st);
   }
+  // Backward of one Linear y = x W^T + b:  dW[N,K] (+)= dy^T x,  db[N] (+)= column sums of dy,  dx[M,K] = dy W (* gelu'(mul)).
+  // Any of dW / db / dx may be null. The fusion head's batch-row problems (fp32) go out as ONE launch of the batch-row
+  // kernel (the bias gradient as dy^T times a ones column, gemm.h b_ones); everything else as the separate calls.
+  int linear_bwd(const void* dy, long lddy, const void* x, long ldx, const void* W, float* dW, float* db, void* dx, long lddx,
+                 int M, int N, int K, int accumulate, const void* mul = nullptr, long ldmul = 0) const {
+    if (dtype == MMSA_F32) {
+      GemmParams ps[3];
+      int n = 0;
+      if (dW) {
+        GemmParams& p = ps[n++];
+        p = blank();
+        p.A = dy; p.lda = lddy; p.a_kmajor = 1; p.B = x; p.ldb = ldx; p.b_kmajor = 1; p.C = dW; p.ldc = K;
+        p.M = N; p.N = K; p.K = M; p.out_f32 = 1; p.accumulate = accumulate;
+      }
+      if (db) {
+        GemmParams& p = ps[n++];
+        p = blank();
+        p.A = dy; p.lda = lddy; p.a_kmajor = 1; p.B = dy; p.ldb = 1; p.b_kmajor = 1; p.b_ones = 1; p.C = db; p.ldc = 1;
+        p.M = N; p.N = 1; p.K = M; p.out_f32 = 1; p.accumulate = accumulate;
+      }
+      if (dx) {
+        GemmParams& p = ps[n++];
+        p = blank();
+        p.A = dy; p.lda = lddy; p.B = W; p.ldb = K; p.b_kmajor = 1; p.C = dx; p.ldc = lddx;
+        p.M = M; p.N = K; p.K = N; p.mul = mul; p.ldmul = ldmul;
+      }
+      if (n >= 2) {
+        const int rc = gemm_f32_tiny_launch_multi(ps, n, st);
+        if (rc != MMSA_ERR_UNSUPPORTED) return rc;
+      }
+    }
+    if (db) RET_IF(bias_grad(dy, lddy, db, M, N, accumulate));
+    if (dW) RET_IF(linear_wgrad(dy, lddy, x, ldx, dW, M, N, K, accumulate));
+    if (dx) RET_IF(linear_dgrad(dy, lddy, W, dx, lddx, M, N, K, mul, ldmul));
+    return MMSA_OK;
+  }
 };

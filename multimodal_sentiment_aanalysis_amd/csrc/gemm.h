@@ -73,6 +73,9 @@ struct GemmParams {
   // in 2-byte units (K = values / 2), the result is scaled by scale_a[0] * scale_b[0] (device scalars). null: bf16 operands.
   const float* scale_a;
   const float* scale_b;
+  // batch-row kernel only (gemm_f32_tiny.hip): B is a [K][1] column of ones that is never read (N must be 1): the product
+  // is the column sum of the k-major A, i.e. a bias gradient as one more problem of a grouped launch
+  int b_ones;
   // optional in-kernel timing record {min start, max end} in s_memrealtime ticks (100 MHz), filled by the MFMA kernels
   // and the split-K reducer when non-null (bench.py roofline: HIP event pairs add ~12 us of queue drain per launch)
   unsigned long long* stamp;
@@ -103,6 +106,9 @@ int gemm_f32_valu_launch(const GemmParams& p, hipStream_t st);  // the VALU-fma 
 // one-launch fp32-MFMA kernel for batch-row problems (gemm_f32_tiny.hip); gemm_f32_launch routes eligible problems to it
 bool gemm_f32_tiny_eligible(const GemmParams& p);
 int gemm_f32_tiny_launch(const GemmParams& p, hipStream_t st);
+// up to 3 independent fp32 batch-row problems (weight gradient + bias gradient + data gradient of one Linear) as ONE launch;
+// MMSA_ERR_UNSUPPORTED when one of them is not eligible (nothing launched)
+int gemm_f32_tiny_launch_multi(const GemmParams* ps, int n, hipStream_t st);
 // the same kernel on bf16 operands (<= 128 rows: BERT pooler, the two projections into the fusion width)
 bool gemm_bf16_tiny_eligible(const GemmParams& p);
 int gemm_bf16_tiny_launch(const GemmParams& p, hipStream_t st);

@@ -42,14 +42,14 @@ __device__ __forceinline__ void tiny_load(const T* __restrict__ X, long ld, int 
   }
 }
 
+// One workgroup's share of one problem: `blk` = its block index inside the problem's tile range
 template <typename T, bool A_KM, bool B_KM>
-__global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmParams p, int KS, int tiles_n, int ntiles) {
-  __shared__ float img[4][256];
+__device__ __forceinline__ void tiny_body(const GemmParams& p, int KS, int tiles_n, int ntiles, int blk, float (*img)[256]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int tpb = 4 / KS;
   const int tib = wave / KS, ks = wave - tib * KS;
-  const int tile = blockIdx.x * tpb + tib;
+  const int tile = blk * tpb + tib;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (tile < ntiles) {
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -64,8 +64,14 @@ __global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmParams p, int KS, in
       for (int u = 0; u < 3; ++u) {
         const int cu = c + u * KS;
         if (cu < nch) {
-          tiny_load<A_KM>(A, p.lda, m, p.M, cu * TY_CHUNK + g * 16, p.K, a[u]);
-          tiny_load<B_KM>(B, p.ldb, n, p.N, cu * TY_CHUNK + g * 16, p.K, b[u]);
+          const int kb = cu * TY_CHUNK + g * 16;
+          tiny_load<A_KM>(A, p.lda, m, p.M, kb, p.K, a[u]);
+          if (B_KM && p.b_ones) {  // the ones column (bias gradient): nothing to read
+#pragma unroll
+            for (int s = 0; s < 16; ++s) b[u][s] = (n == 0 && kb + s < p.K) ? 1.f : 0.f;
+          } else {
+            tiny_load<B_KM>(B, p.ldb, n, p.N, kb, p.K, b[u]);
+          }
         }
       }
 #pragma unroll
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmParams p, int KS, in
   __syncthreads();
   const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
   for (int t = 0; t < tpb; ++t) {
-    const int tl = blockIdx.x * tpb + t;
+    const int tl = blk * tpb + t;
     if (tl >= ntiles) break;
     const int tm = tl / tiles_n, tn = tl - tm * tiles_n;
     const int m = tm * 16 + row, n = tn * 16 + col;
@@ -93,10 +99,43 @@ __global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmParams p, int KS, in
   }
 }
 
+template <typename T, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmParams p, int KS, int tiles_n, int ntiles) {
+  __shared__ float img[4][256];
+  tiny_body<T, A_KM, B_KM>(p, KS, tiles_n, ntiles, blockIdx.x, img);
+}
+
+// Up to 3 problems of any operand layout in one launch (the backward of one Linear: dW = dy^T x, db = dy^T 1, dx = dy W):
+// a workgroup belongs to exactly one problem (block ranges), so the layout dispatch is workgroup-uniform.
+#define TINY_MAX_PROBS 3
+struct TinyBatch {
+  GemmParams p[TINY_MAX_PROBS];
+  int blk_begin[TINY_MAX_PROBS + 1];
+  int KS[TINY_MAX_PROBS], tiles_n[TINY_MAX_PROBS], ntiles[TINY_MAX_PROBS];
+  int n;
+};
+__global__ __launch_bounds__(256) void gemm_tiny_multi_kernel(TinyBatch tb) {
+  __shared__ float img[4][256];
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < TINY_MAX_PROBS; ++i)
+    if (i < tb.n && (int)blockIdx.x >= tb.blk_begin[i]) q = i;
+  const GemmParams& p = tb.p[q];
+  const int blk = blockIdx.x - tb.blk_begin[q];
+  if (p.a_kmajor) {
+    if (p.b_kmajor) tiny_body<float, true, true>(p, tb.KS[q], tb.tiles_n[q], tb.ntiles[q], blk, img);
+    else tiny_body<float, true, false>(p, tb.KS[q], tb.tiles_n[q], tb.ntiles[q], blk, img);
+  } else {
+    if (p.b_kmajor) tiny_body<float, false, true>(p, tb.KS[q], tb.tiles_n[q], tb.ntiles[q], blk, img);
+    else tiny_body<float, false, false>(p, tb.KS[q], tb.tiles_n[q], tb.ntiles[q], blk, img);
+  }
+}
+
 template <typename T>
 static bool tiny_eligible(const GemmParams& p) {
   static const bool off = [] { const char* v = getenv("MMSA_F32_TINY"); return v && atoi(v) == 0; }();
   if (off || p.gather != 0 || p.c_gw > 0 || p.M <= 0 || p.N <= 0 || p.K <= 0 || p.scale_a) return false;
+  if (p.b_ones && (!p.b_kmajor || p.N != 1 || sizeof(T) != 4)) return false;
   // beyond: operand re-reads (no LDS sharing between the tiles of a workgroup) start to cost.  bf16: one notch higher so
   // that the BERT pooler (64 x 768 x 768) is in
   if ((double)p.M * p.N * p.K > (double)(1 << (sizeof(T) == 4 ? 25 : 26))) return false;
@@ -129,3 +168,28 @@ static int tiny_launch(const GemmParams& pin, hipStream_t st) {
 }
 int gemm_f32_tiny_launch(const GemmParams& p, hipStream_t st) { return tiny_launch<float>(p, st); }
 int gemm_bf16_tiny_launch(const GemmParams& p, hipStream_t st) { return tiny_launch<bf16>(p, st); }
+
+int gemm_f32_tiny_launch_multi(const GemmParams* ps, int n, hipStream_t st) {
+  if (n < 1 || n > TINY_MAX_PROBS) return MMSA_ERR_UNSUPPORTED;
+  TinyBatch tb;
+  tb.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!tiny_eligible<float>(ps[i])) return MMSA_ERR_UNSUPPORTED;
+    GemmParams& p = tb.p[i];
+    p = ps[i];
+    p.split_k = 1;
+    p.ws = nullptr;
+    const int tiles_m = cdiv(p.M, 16);
+    tb.tiles_n[i] = cdiv(p.N, 16);
+    tb.ntiles[i] = tiles_m * tb.tiles_n[i];
+    tb.KS[i] = p.K >= 256 ? 4 : (p.K >= 128 ? 2 : 1);
+    tb.blk_begin[i] = blocks;
+    blocks += cdiv(tb.ntiles[i], 4 / tb.KS[i]);
+  }
+  for (int i = n; i <= TINY_MAX_PROBS; ++i) tb.blk_begin[i] = blocks;
+  for (int i = n; i < TINY_MAX_PROBS; ++i) { tb.p[i] = tb.p[0]; tb.KS[i] = 1; tb.tiles_n[i] = 1; tb.ntiles[i] = 0; }
+  hipLaunchKernelGGL(gemm_tiny_multi_kernel, dim3(blocks), dim3(256), 0, st, tb);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}

@@ -118,12 +118,8 @@ struct HCtx {
   // dx may be null (input needs no gradient); mul = pre-activation for a fused gelu'
   int lin_bwd(const LinP& l, const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, int M,
               const float* mul = nullptr, long ldmul = 0) const {
-    if (g) {
-      RET_IF(e.bias_grad(dy, lddy, G(l.b), M, l.out, acc));
-      RET_IF(e.linear_wgrad(dy, lddy, x, ldx, G(l.w), M, l.out, l.in, acc));
-    }
-    if (dx) RET_IF(e.linear_dgrad(dy, lddy, P(l.w), dx, lddx, M, l.out, l.in, mul, ldmul));
-    return MMSA_OK;
+    return e.linear_bwd(dy, lddy, x, ldx, P(l.w), g ? G(l.w) : nullptr, g ? G(l.b) : nullptr, dx, lddx, M, l.out, l.in, acc, mul,
+                        ldmul);
   }
   int bn_fwd(const BnP& b, const float* x, float* y, float* mean, float* invstd, int M, int act) const {
     return bn_forward(MMSA_F32, x, P(b.g), P(b.b), bn + b.rm, bn + b.rv, mean, invstd, nullptr, y, bnws, M, b.c, c.bn_eps,
@@ -299,27 +295,21 @@ static int cross_bwd(const HCtx& h, const HeadLayout& L, HeadWs& w, const float*
   RET_IF(ew2d(EW_ADD, w.dcat + E, 2 * E, w.dctx, E, w.dmix, E, B, E, e.st));     // d attn_out
   // out-projection
   const bool one_key = (Lk == 1);
-  if (h.g) {
-    RET_IF(e.bias_grad(w.dmix, E, h.G(L.mha.outb), B, E, h.acc));
-    RET_IF(e.linear_wgrad(w.dmix, E, one_key ? w.vp : w.ctx, E, h.G(L.mha.outw), B, E, E, h.acc));
-  }
+  // out-projection backward (one launch): d(context) lands in dvp when the context was the projected value itself
+  RET_IF(e.linear_bwd(w.dmix, E, one_key ? w.vp : w.ctx, E, h.P(L.mha.outw), h.g ? h.G(L.mha.outw) : nullptr,
+                      h.g ? h.G(L.mha.outb) : nullptr, one_key ? w.dvp : w.dctx, E, B, E, E, h.acc));
   if (one_key) {
     // context == projected value (cross_fwd): d(projected value) = d(context); the query / key projections get exactly zero
     // gradient (softmax over one key: p (dp - p dp) = 0), the key input too; the query only through its direct paths (dq2)
-    RET_IF(e.linear_dgrad(w.dmix, E, h.P(L.mha.outw), w.dvp, E, B, E, E));
-    if (h.g) {
-      if (!h.acc) {  // overwrite mode: the zero gradients must be written
-        if (hipMemsetAsync(h.G(L.mha.inw), 0, (size_t)2 * E * E * sizeof(float), e.st) != hipSuccess) return MMSA_ERR_LAUNCH;
-        if (hipMemsetAsync(h.G(L.mha.inb), 0, (size_t)2 * E * sizeof(float), e.st) != hipSuccess) return MMSA_ERR_LAUNCH;
-      }
-      RET_IF(e.bias_grad(w.dvp, E, h.G(L.mha.inb) + 2 * E, B, E, h.acc));
-      RET_IF(e.linear_wgrad(w.dvp, E, v, E, h.G(L.mha.inw) + 2L * E * E, B, E, E, h.acc));
+    if (h.g && !h.acc) {  // overwrite mode: the zero gradients must be written
+      if (hipMemsetAsync(h.G(L.mha.inw), 0, (size_t)2 * E * E * sizeof(float), e.st) != hipSuccess) return MMSA_ERR_LAUNCH;
+      if (hipMemsetAsync(h.G(L.mha.inb), 0, (size_t)2 * E * sizeof(float), e.st) != hipSuccess) return MMSA_ERR_LAUNCH;
     }
     RET_IF(ew2d(EW_COPY, w.dq2, E, nullptr, 0, din[0], E, B, E, e.st));
     if (hipMemsetAsync(din[1], 0, (size_t)B * E * sizeof(float), e.st) != hipSuccess) return MMSA_ERR_LAUNCH;
-    return e.linear_dgrad(w.dvp, E, h.P(L.mha.inw) + 2L * E * E, din[2], E, B, E, E);
+    return e.linear_bwd(w.dvp, E, v, E, h.P(L.mha.inw) + 2L * E * E, h.g ? h.G(L.mha.inw) + 2L * E * E : nullptr,
+                        h.g ? h.G(L.mha.inb) + 2 * E : nullptr, din[2], E, B, E, E, h.acc);
   }
-  RET_IF(e.linear_dgrad(w.dmix, E, h.P(L.mha.outw), w.dctx, E, B, E, E));
   RET_IF(mha_core_bwd(w.qp, E, w.kp, E, w.vp, E, w.probs, w.dctx, E, w.dqp, E, w.dkp, E, w.dvp, E, B, 1, Lk, E, h.c.heads, e.st));
   // in-projection (three row blocks of the packed weight)
   if (h.g) {
@@ -359,18 +349,12 @@ static int mmf_bwd(const HCtx& h, const HeadLayout& L, HeadWs& w, const float* c
   const Eng& e = h.e;
   RET_IF(lrb_bwd(h, L.fm0, L.fm2, dout[0], w.pooled, E, w.fm, 0.f, w.dpooled, E, B));
   RET_IF(seq_pool_bwd(w.dpooled, w.pidx, w.dattn, B, M, E, h.c.pool_mode, e.st));
-  if (h.g) {
-    RET_IF(e.bias_grad(w.dattn, E, h.G(L.mha.outb), B * M, E, h.acc));
-    RET_IF(e.linear_wgrad(w.dattn, E, w.ctx, E, h.G(L.mha.outw), B * M, E, E, h.acc));
-  }
-  RET_IF(e.linear_dgrad(w.dattn, E, h.P(L.mha.outw), w.dctx1, E, B * M, E, E));
+  RET_IF(e.linear_bwd(w.dattn, E, w.ctx, E, h.P(L.mha.outw), h.g ? h.G(L.mha.outw) : nullptr, h.g ? h.G(L.mha.outb) : nullptr,
+                      w.dctx1, E, B * M, E, E, h.acc));
   RET_IF(mha_core_bwd(w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.probs, w.dctx1, E, w.dqkv, 3 * E, w.dqkv + E, 3 * E,
                       w.dqkv + 2 * E, 3 * E, B, M, M, E, h.c.heads, e.st));
-  if (h.g) {
-    RET_IF(e.bias_grad(w.dqkv, 3 * E, h.G(L.mha.inb), B * M, 3 * E, h.acc));
-    RET_IF(e.linear_wgrad(w.dqkv, 3 * E, w.seqn, E, h.G(L.mha.inw), B * M, 3 * E, E, h.acc));
-  }
-  RET_IF(e.linear_dgrad(w.dqkv, 3 * E, h.P(L.mha.inw), w.dseq, E, B * M, 3 * E, E));
+  RET_IF(e.linear_bwd(w.dqkv, 3 * E, w.seqn, E, h.P(L.mha.inw), h.g ? h.G(L.mha.inw) : nullptr, h.g ? h.G(L.mha.inb) : nullptr,
+                      w.dseq, E, B * M, 3 * E, E, h.acc));
   for (int m = 0; m < M; ++m) {
     // modality m's rows sit at stride M*E in the token sequence
     RET_IF(l2norm_bwd_ld(w.dseq + (long)m * E, w.seqn + (long)m * E, (long)M * E, w.nrm + (long)m * B, din[m], B, E, 1e-12f, 0,
