@@ -17,8 +17,15 @@
 #define TY_CHUNK 64
 
 template <bool KM, typename T>
-__device__ __forceinline__ void tiny_load(const T* __restrict__ X, long ld, int x, int X_n, int kb, int K, float* v) {
+__device__ __forceinline__ void tiny_load(const T* __restrict__ X, long ld, int x, int X_n, int kb, int K, float* v, bool vec) {
   // X_n: extent of the non-contracted dimension; x: this lane's row / column in it; kb: first of the lane's 16 k-values
+  // vec (workgroup-uniform): the k-contiguous rows can be read 16 bytes at a time (K, ld multiples of the vector, base aligned)
+  if (!KM && !vec) {  // e.g. the data gradient of a 3-class head: K = 3
+    const T* row = X + (long)x * ld + kb;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = (x < X_n && kb + s < K) ? to_f32<T>(row[s]) : 0.f;
+    return;
+  }
   if constexpr (!KM && sizeof(T) == 4) {
     const float* row = (const float*)X + (long)x * ld + kb;
 #pragma unroll
@@ -57,6 +64,9 @@ __device__ __forceinline__ void tiny_body(const GemmParams& p, int KS, int tiles
     const T* A = (const T*)p.A;
     const T* B = (const T*)p.B;
     const int nch = (p.K + TY_CHUNK - 1) / TY_CHUNK;
+    constexpr int V = 16 / sizeof(T);
+    const bool vec_a = !(p.K % V) && !(p.lda % V) && !((uintptr_t)p.A & 15);
+    const bool vec_b = !(p.K % V) && !(p.ldb % V) && !((uintptr_t)p.B & 15);
     // up to three chunks per wave in flight at once (K <= 768 with the 4-way split: ONE memory round trip per launch)
     float a[3][16], b[3][16];
     for (int c = ks; c < nch; c += 3 * KS) {
@@ -65,12 +75,12 @@ __device__ __forceinline__ void tiny_body(const GemmParams& p, int KS, int tiles
         const int cu = c + u * KS;
         if (cu < nch) {
           const int kb = cu * TY_CHUNK + g * 16;
-          tiny_load<A_KM>(A, p.lda, m, p.M, kb, p.K, a[u]);
+          tiny_load<A_KM>(A, p.lda, m, p.M, kb, p.K, a[u], vec_a);
           if (B_KM && p.b_ones) {  // the ones column (bias gradient): nothing to read
 #pragma unroll
             for (int s = 0; s < 16; ++s) b[u][s] = (n == 0 && kb + s < p.K) ? 1.f : 0.f;
           } else {
-            tiny_load<B_KM>(B, p.ldb, n, p.N, kb, p.K, b[u]);
+            tiny_load<B_KM>(B, p.ldb, n, p.N, kb, p.K, b[u], vec_b);
           }
         }
       }
@@ -139,10 +149,7 @@ static bool tiny_eligible(const GemmParams& p) {
   // beyond: operand re-reads (no LDS sharing between the tiles of a workgroup) start to cost.  bf16: one notch higher so
   // that the BERT pooler (64 x 768 x 768) is in
   if ((double)p.M * p.N * p.K > (double)(1 << (sizeof(T) == 4 ? 25 : 26))) return false;
-  constexpr int V = 16 / sizeof(T);  // elements per 16-byte load
-  if (!p.a_kmajor && ((p.K % V) || (p.lda % V) || ((uintptr_t)p.A & 15))) return false;
-  if (!p.b_kmajor && ((p.K % V) || (p.ldb % V) || ((uintptr_t)p.B & 15))) return false;
-  return true;
+  return true;  // any stride / alignment: rows that cannot be read 16 bytes at a time take the scalar loads
 }
 bool gemm_f32_tiny_eligible(const GemmParams& p) { return tiny_eligible<float>(p); }
 bool gemm_bf16_tiny_eligible(const GemmParams& p) {
