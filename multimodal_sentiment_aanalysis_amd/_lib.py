@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmmsa_hip.so")
+# MMSA_LIB: another build of the same library (timing ablations: tools/microbench/ablate_nomfma.sh); default = the in-tree one
+LIB_PATH = os.environ.get("MMSA_LIB") or os.path.join(_HERE, "lib", "libmmsa_hip.so")
 
 MMSA_F32, MMSA_BF16, MMSA_FP8 = 0, 1, 2
 GEMM_F32_SIMT, GEMM_BF16_MFMA, GEMM_BF16_SIMT, GEMM_F32_MFMA, GEMM_F32_VALU = 0, 1, 2, 3, 4

@@ -658,6 +658,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     }
   };
   auto mma1 = [&](const bf16x8& fbj, const bf16x8& fai, f32x4 c) __attribute__((always_inline)) -> f32x4 {
+#ifdef G2_ABLATE_NO_MFMA  // timing-only build (tools/microbench/ablate_nomfma.sh): the loop without its matrix instructions;
+    asm volatile("" ::"v"(fbj), "v"(fai));  // the fragments stay live, so the LDS reads are not dropped with them
+    return c;
+#endif
     if constexpr (FP8) {
       typedef __attribute__((ext_vector_type(2))) long i64x2_;
       const i64x2_ b2 = __builtin_bit_cast(i64x2_, fbj), a2 = __builtin_bit_cast(i64x2_, fai);
