@@ -14,6 +14,9 @@ Pinning status:
     /root/reference in this container (tests/golden/make_golden.py -> tests/golden/*.npz).
   * BERT-base (E1): not in the reference; pinned against transformers==5.15.0 BertModel (config-only, random
     init) by the same script. For the reference itself: "parity unpinned".
-  * ResNet-50 v1.5 (E2): not in the reference and no torchvision in the image: "parity unpinned" — anchored on
-    the canonical parameter count (23 508 032 without fc) and finite-difference gradient checks.
+  * ResNet-50 v1.5 (E2): not in the reference (for the reference itself: "parity unpinned"); pinned against
+    transformers==5.15.0 ResNetModel (config-only, downsample_in_bottleneck=False = v1.5, run in float64) by the same
+    script: a mini net with stored weights (outputs, every gradient, BN running statistics, eval mode) and full
+    ResNet-50 with seed-regenerated weights (tests/golden/e2_resnet_*.npz; the float64 oracle reproduces them to
+    1e-12, tests/test_oracle_golden.py).
 """

@@ -1,7 +1,9 @@
 """ResNet-50 v1.5 image encoder restated with torch.nn.functional conv/pool primitives (TEST INFRASTRUCTURE ONLY).
 
-NOT IN THE REFERENCE: /root/reference contains no ResNet and torchvision is not installed, so this is
-"parity unpinned" (oracle/__init__.py). It restates the public architecture (He et al. 2015; v1.5 = stride on
+NOT IN THE REFERENCE: /root/reference contains no ResNet (w.r.t. the reference: "parity unpinned"). Pinned against the
+third-party transformers==5.15.0 `ResNetModel(ResNetConfig(downsample_in_bottleneck=False))` run in float64
+(tests/golden/make_golden.py::gen_resnet -> e2_resnet_mini.npz, e2_resnet50_seed1234.npz; tests/test_oracle_golden.py:
+outputs, every parameter gradient, BN running statistics, eval mode: 1e-12 in float64). It restates the public architecture (He et al. 2015; v1.5 = stride on
 the 3x3 conv of each downsampling bottleneck): 7x7/2 conv(3->64)+BN+ReLU, 3x3/2 max-pool (pad 1), stages of
 [3,4,6,3] bottlenecks (1x1 -> 3x3 -> 1x1(x4), BN after each conv, ReLU after the first two and after the
 residual add; 1x1 strided conv + BN downsample on the first block of a stage), global average pool -> [B,2048].

@@ -253,6 +253,115 @@ def gen_bert():
         hidden_row5=ob.last_hidden_state[5])
 
 
+# ------------------------------------------------------------------------------------------------ E2 (not in reference)
+def tv_to_hf_resnet(name):
+    """torchvision-style ResNet key (the oracle's / the product's names, no prefix) -> transformers.ResNetModel key."""
+    sub = {"weight": "weight", "bias": "bias", "running_mean": "running_mean", "running_var": "running_var",
+           "num_batches_tracked": "num_batches_tracked"}
+    parts = name.split(".")
+    if parts[0] == "conv1":
+        return "embedder.embedder.convolution.weight"
+    if parts[0] == "bn1":
+        return "embedder.embedder.normalization." + parts[1]
+    s, b = int(parts[0][len("layer"):]) - 1, int(parts[1])
+    base = f"encoder.stages.{s}.layers.{b}."
+    if parts[2] == "downsample":
+        return base + ("shortcut.convolution.weight" if parts[3] == "0" else "shortcut.normalization." + parts[4])
+    k = int(parts[2][-1]) - 1
+    return base + f"layer.{k}." + ("convolution.weight" if parts[2].startswith("conv") else "normalization." + parts[3])
+
+
+def gen_resnet():
+    """E2 pin: transformers.ResNetModel (config-only construction, local code, no fetch) is ResNet v1.5 with
+    downsample_in_bottleneck=False (stride on the 3x3) — the same public architecture oracle/resnet.py restates. Two fixtures:
+    a mini net with STORED weights (train-mode pooled output + per-stage maps, every parameter gradient of a fixed scalar,
+    BN running statistics after that forward, eval-mode output with those statistics), and full ResNet-50 with weights
+    REGENERATED from a seed by the product's initialiser on both sides (outputs + strided gradient samples only).
+    transformers.ResNetModel is run in FLOAT64 (weights and inputs are exact fp32 values), so the fixture is the exact function:
+    a random-init BatchNorm ResNet amplifies fp32 summation-order noise to ~1e-2 in the gradients, which
+    would otherwise be the floor of every comparison against it."""
+    from transformers import ResNetConfig, ResNetModel
+    from multimodal_sentiment_aanalysis_amd.engine import RESNET50, ResNetImageNet
+    from oracle.resnet import resnet_param_shapes
+
+    def hf_model(cfg):
+        c = ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[4 * w for w in cfg["widths"]],
+                         depths=list(cfg["blocks"]), layer_type="bottleneck", hidden_act="relu",
+                         downsample_in_first_stage=False, downsample_in_bottleneck=False)
+        return ResNetModel(c)
+
+    def load_tv(hf, sd_tv):
+        ocfg = dict(blocks=tuple(hf.config.depths), widths=tuple(h // 4 for h in hf.config.hidden_sizes), expansion=4)
+        mapped = {tv_to_hf_resnet(n): sd_tv[n] for n, _, _ in resnet_param_shapes(ocfg)}
+        res = hf.load_state_dict(mapped, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys, res
+        return ocfg
+
+    def hf_to_tv(hf, ocfg):
+        sd = hf.state_dict()
+        return {n: sd[tv_to_hf_resnet(n)].clone() for n, _, _ in resnet_param_shapes(ocfg)}
+
+    # ---- mini net, stored weights ---------------------------------------------------------------------------------
+    mini = dict(blocks=(1, 2, 1, 1), widths=(64, 64, 128, 128))
+    torch.manual_seed(21)
+    hf = hf_model(mini)
+    ocfg = dict(blocks=mini["blocks"], widths=mini["widths"], expansion=4)
+    with torch.no_grad():  # non-trivial BN affine parameters and running statistics
+        for n, p in hf.named_parameters():
+            if "normalization" in n:
+                p.add_(0.1 * torch.randn_like(p))
+        for n, b in hf.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn_like(b))
+            if n.endswith("running_var"):
+                b.copy_(1.0 + 0.2 * torch.rand_like(b))
+    w0 = hf_to_tv(hf, ocfg)
+    image = rnd(4, 3, 96, 96, seed=22)
+    wgt = rnd(4, 512, seed=23)
+    hf.double().train()
+    out = hf(pixel_values=image.double(), output_hidden_states=True)
+    pooled = out.pooler_output.flatten(1)
+    (pooled * wgt.double()).sum().backward()
+    g = {n: dict(hf.named_parameters())[tv_to_hf_resnet(n)].grad.clone()
+         for n, _, buf in resnet_param_shapes(ocfg) if not buf}
+    w1 = hf_to_tv(hf, ocfg)  # running statistics after one train-mode forward
+    hf.eval()
+    with torch.no_grad():
+        pooled_eval = hf(pixel_values=image.double()).pooler_output.flatten(1)
+    npz("e2_resnet_mini.npz", image=image, wgt=wgt, pooled_train=pooled, pooled_eval=pooled_eval,
+        **{f"stage{i}": h.float() for i, h in enumerate(out.hidden_states)},
+        **{"w." + k: v for k, v in w0.items()}, **{"g." + k: v.float() for k, v in g.items()},
+        **{"w1." + k: v for k, v in w1.items() if "running" in k or "num_batches" in k})
+
+    # ---- ResNet-50, weights regenerated from a seed by the product's initialiser ------------------------------------
+    torch.manual_seed(1234)
+    net = ResNetImageNet(RESNET50)
+    sd = {k[len("resnet."):]: v.detach().clone().contiguous() for k, v in net.state_dict().items() if k.startswith("resnet.")}
+    hfb = hf_model(RESNET50)
+    ocfg = load_tv(hfb, sd)
+    assert sum(p.numel() for p in hfb.parameters()) == 23508032
+    image = rnd(4, 3, 224, 224, seed=24)
+    wgt = rnd(4, 2048, seed=25)
+    hfb.double().train()
+    out = hfb(pixel_values=image.double())
+    pooled = out.pooler_output.flatten(1)
+    (pooled * wgt.double()).sum().backward()
+    arrays = {}
+    hp = dict(hfb.named_parameters())
+    for n, _, buf in resnet_param_shapes(ocfg):
+        if buf:
+            continue
+        gr = hp[tv_to_hf_resnet(n)].grad.reshape(-1)
+        stride = max(1, gr.numel() // 512)
+        arrays["gn." + n] = gr.norm()
+        arrays["gs." + n] = gr[::stride][:512].clone()
+    hfb.eval()
+    with torch.no_grad():
+        pooled_eval = hfb(pixel_values=image.double()).pooler_output.flatten(1)
+    npz("e2_resnet50_seed1234.npz", image_seed=torch.tensor(24), wgt=wgt, pooled_train=pooled, pooled_eval=pooled_eval,
+        last_map_b0=out.last_hidden_state[0, ::64], **arrays)
+
+
 # ------------------------------------------------------------------------------------------------ N1
 def gen_contrastive():
     """N1: the reference's two contrastive losses, CALLED: MultimodalTransformerModel.compute_contrastive_loss
@@ -332,7 +441,7 @@ def gen_multitask_phases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["a1", "a2", "a4", "a5", "a7", "e1", "n1", "n2"]
+    which = sys.argv[1:] or ["a1", "a2", "a4", "a5", "a7", "e1", "e2", "n1", "n2"]
     if "n2" in which:
         gen_multitask_phases()
     if "n1" in which:
@@ -349,3 +458,5 @@ if __name__ == "__main__":
         gen_train_step()
     if "e1" in which:
         gen_bert()
+    if "e2" in which:
+        gen_resnet()

@@ -245,6 +245,89 @@ def test_e1_bert_base_seed_regenerated(dev):
     assert err < 5e-2
 
 
+def _identity_proj(net, width):
+    with torch.no_grad():
+        net._pmap["proj.weight"].copy_(torch.eye(width))
+        net._pmap["proj.bias"].zero_()
+
+
+def test_e2_resnet_mini_against_transformers(dev):
+    """E2 on the device against the transformers.ResNetModel (float64) golden, stored weights: train-mode features, every
+    parameter gradient, running statistics after the forward, eval-mode features with those statistics. The projection is
+    the identity so that the engine's [B, out_dim] output IS the pooled feature vector."""
+    from multimodal_sentiment_aanalysis_amd.engine import ResNetImageNet
+    d = load("e2_resnet_mini.npz")
+    rcfg = dict(blocks=(1, 2, 1, 1), widths=(64, 64, 128, 128))
+    for precision, tol_f, tol_g, tol_s in (("fp32", 1e-4, 5e-3, 1e-4), ("bf16", 3e-2, 3e-1, 3e-2)):
+        net = ResNetImageNet(rcfg, out_dim=512)
+        net.precision = precision
+        sd = {"resnet." + k: v.clone() for k, v in sub(d, "w.").items()}
+        sd["proj.weight"], sd["proj.bias"] = torch.eye(512), torch.zeros(512)
+        net.load_state_dict(sd)
+        net.to(dev).train()
+        out = net(d["image"].to(dev))
+        close(out, d["pooled_train"], tol_f, f"{precision} pooled (train)")
+        (out * d["wgt"].to(dev)).sum().backward()
+        gs = sub(d, "g.")
+        gmax = max(v.abs().max().item() for v in gs.values())
+        worst = ("", 0.0)
+        for n, p in net.named_parameters():
+            if not n.startswith("resnet."):
+                continue
+            r = gs[n[len("resnet."):]].double()
+            e = ((p.grad.detach().cpu().double() - r).norm() / r.norm().clamp_min(1e-3 * gmax * r.numel() ** 0.5)).item()
+            worst = max(worst, (n, e), key=lambda t: t[1])
+        assert worst[1] < tol_g, f"{precision}: worst gradient rel-L2 {worst[1]:.3e} at {worst[0]}"
+        post = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        for k, v in sub(d, "w1.").items():
+            if "num_batches" in k:
+                assert int(post["resnet." + k]) == int(v)
+            else:
+                close(post["resnet." + k], v, tol_s, f"{precision} running statistic {k}")
+        net.eval()
+        with torch.no_grad():
+            ev = net(d["image"].to(dev))
+        close(ev, d["pooled_eval"], tol_f, f"{precision} pooled (eval)")
+        print(f"e2 mini {precision}: worst gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
+
+
+def test_e2_resnet50_seed_regenerated(dev):
+    """ResNet-50 at full size (B=4, 224x224) against transformers.ResNetModel in float64: weights regenerated from seed 1234 on
+    both sides. fp32 engine: pooled features <= 1e-4 (train and eval); gradients within the fp32 summation-order floor of this
+    random-init network (the fp32 CPU oracle itself is 2.5e-2 from the float64 values: tests/test_oracle_golden.py), asserted at
+    2x that. bf16 engine: features bounded by the bf16-policy oracle's own distance (~0.3 free-running)."""
+    from multimodal_sentiment_aanalysis_amd.engine import RESNET50, ResNetImageNet
+    d = load("e2_resnet50_seed1234.npz")
+    image = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(int(d["image_seed"])))
+    for precision, tol_f, tol_g in (("fp32", 1e-4, 5e-2), ("bf16", 0.6, None)):
+        torch.manual_seed(1234)
+        net = ResNetImageNet(RESNET50, out_dim=2048)
+        net.precision = precision
+        _identity_proj(net, 2048)
+        net.to(dev).train()
+        out = net(image.to(dev))
+        close(out, d["pooled_train"], tol_f, f"ResNet-50 {precision} pooled (train)")
+        if tol_g is not None:
+            (out * d["wgt"].float().to(dev)).sum().backward()
+            worst, nworst = ("", 0.0), 0.0
+            for n, p in net.named_parameters():
+                if not n.startswith("resnet."):
+                    continue
+                k = n[len("resnet."):]
+                g = p.grad.detach().cpu().reshape(-1)  # logical OIHW order (the storage is channels_last)
+                stride = max(1, g.numel() // 512)
+                e = ((g[::stride][:512].double() - d["gs." + k]).norm() / (d["gs." + k].norm() + 1e-30)).item()
+                worst = max(worst, (n, e), key=lambda t: t[1])
+                nworst = max(nworst, abs(g.double().norm().item() - d["gn." + k].item()) / d["gn." + k].item())
+            print(f"ResNet-50 {precision} vs transformers float64: worst gradient-sample rel-L2 {worst[1]:.2e} ({worst[0]}), "
+                  f"worst norm error {nworst:.2e}")
+            assert worst[1] < tol_g and nworst < 2e-2, (worst, nworst)
+        net.eval()
+        with torch.no_grad():
+            ev = net(image.to(dev))
+        close(ev, d["pooled_eval"], 1e-4 if precision == "fp32" else 3e-2, f"ResNet-50 {precision} pooled (eval)")
+
+
 def test_trainer_and_tester_contracts(dev, tmp_path):
     from multimodal_sentiment_aanalysis_amd.dataLoader import MultimodalDataLoader
     from multimodal_sentiment_aanalysis_amd.Tester import Tester
