@@ -305,15 +305,19 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
     const bool last_needed = (l == lowest);  // nothing trainable below: this layer's input needs no gradient
     void* ds2 = bB;
     // ds2 is also dY of the FFN output Linear: its bias gradient (column sums of ds2) comes out of the same pass
-    RET_IF(layernorm_bwd(sdt(c), dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, G(f.ln2w), G(f.ln2b), acc, ws.lnws, M, H, st,
-                         G(f.b2)));
+    // (a wholly frozen layer produces NO parameter gradient: its LayerNorm / bias gradient outputs are null, so that stale
+    //  gradients of an earlier phase stay what torch would keep and a data-parallel replica never steps an un-reduced range)
+    const bool lf = layer_frozen[l];
+    RET_IF(layernorm_bwd(sdt(c), dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, lf ? nullptr : G(f.ln2w),
+                         lf ? nullptr : G(f.ln2b), acc, ws.lnws, M, H, st, lf ? nullptr : G(f.b2)));
     void* dpre = ws.bufI;
     RET_IF(e.linear_dgrad(ds2, H, W(f.w2), dpre, I, M, H, I, a.pre, I, nullptr, 0, gelu_factor()));  // * gelu'(pre), stored by the forward
     void* dh1 = bC;
     RET_IF(e.linear_dgrad(dpre, I, W(f.w1), dh1, H, M, I, H, nullptr, 0, ds2, H));  // + residual branch
     void* ds1 = dOut;
-    RET_IF(layernorm_bwd(sdt(c), dh1, a.s1, a.mean1, a.rstd1, P(f.ln1w), ds1, G(f.ln1w), G(f.ln1b), acc, ws.lnws, M, H, st,
-                         G(f.bo)));  // + bias gradient of the attention output Linear
+    RET_IF(layernorm_bwd(sdt(c), dh1, a.s1, a.mean1, a.rstd1, P(f.ln1w), ds1, lf ? nullptr : G(f.ln1w),
+                         lf ? nullptr : G(f.ln1b), acc, ws.lnws, M, H, st,
+                         lf ? nullptr : G(f.bo)));  // + bias gradient of the attention output Linear
     void* dctx = ws.bufD;
     RET_IF(e.linear_dgrad(ds1, H, W(f.wo), dctx, H, M, H, H));
     void* dqkv = ws.bufQ;

@@ -139,7 +139,8 @@ int mmsa_grad_scale_clip(float* g, int64_t n, const float* norm_clip, void* stre
 int mmsa_adamw_step_dev(float* w, const float* g, float* m, float* v, void* w16, int64_t n, float lr, float beta1, float beta2,
                         float eps, float weight_decay, const int32_t* step_count, const float* norm_clip, float grad_scale,
                         void* stream) {
-  if (!w || !g || !m || !v || !step_count) return MMSA_ERR_ARG;
+  // with a device step count the kernel reads the bias corrections from norm_clip[2..3] (written by the norm's finalize)
+  if (!w || !g || !m || !v || !step_count || !norm_clip) return MMSA_ERR_ARG;
   return adamw_step(w, g, m, v, w16, n, lr, beta1, beta2, eps, weight_decay, 0, norm_clip, grad_scale, (hipStream_t)stream,
                     step_count);
 }

@@ -138,18 +138,30 @@ __device__ __forceinline__ float block_max256(float m, float* red) {
 __global__ __launch_bounds__(256) void fp8_amax_kernel(const bf16* __restrict__ x, long n8, float* __restrict__ part) {
   __shared__ float red[4];
   float m = 0.f;
+  bool bad = false;  // a NaN / Inf element: fmaxf would drop the NaN and the clamp would turn it into a finite value, hiding a
+                     // fault from the trainer's NaN rule (Trainer.py:74-76). The maximum becomes +Inf instead: scale = Inf,
+                     // every product 0 * Inf or finite * Inf, so the Linear's output is non-finite and the step is skipped.
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   for (; i + stride < n8; i += 2 * stride) {  // two 16-byte loads in flight per lane
     const bf16x8 v = *(const bf16x8*)(x + i * 8), w = *(const bf16x8*)(x + (i + stride) * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(fabsf((float)v[e]), fabsf((float)w[e])));
+    for (int e = 0; e < 8; ++e) {
+      const float a = fabsf((float)v[e]), b = fabsf((float)w[e]);
+      bad |= !(a <= 3.0e38f) | !(b <= 3.0e38f);
+      m = fmaxf(m, fmaxf(a, b));
+    }
   }
   if (i < n8) {
     const bf16x8 v = *(const bf16x8*)(x + i * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[e]));
+    for (int e = 0; e < 8; ++e) {
+      const float a = fabsf((float)v[e]);
+      bad |= !(a <= 3.0e38f);
+      m = fmaxf(m, a);
+    }
   }
+  if (bad) m = __builtin_inff();
   m = block_max256(m, red);
   if (threadIdx.x == 0) part[blockIdx.x] = m;
 }

@@ -290,11 +290,12 @@ static int bn_fwd(const ResCtx& r, const ConvDef& c, const ConvWs& w, const void
   return bn_forward(r.c.dtype, w.z, r.P(c.g), r.P(c.b), r.bnbuf + c.rm, r.bnbuf + c.rv, w.mean, w.invstd, res, y, bnws, M,
                     c.Cout, r.c.bn_eps, r.c.bn_momentum, act, r.c.training, r.e.st, bn_mask(w, act));
 }
+// param_grads = false (a wholly frozen bottleneck): only the data gradient is produced, dgamma / dbeta are not written
 static int bn_bwd(const ResCtx& r, const ConvDef& c, const ConvWs& w, const void* dy, const void* y, void* dz, void* dres,
-                  int act, float* bnws) {
+                  int act, float* bnws, bool param_grads = true) {
   const int M = r.c.batch * c.Hout * c.Wout;
-  return bn_backward(r.c.dtype, dy, w.z, y, w.mean, w.invstd, r.P(c.g), r.P(c.b), dz, dres, r.G(c.g), r.G(c.b), r.acc, bnws,
-                     M, c.Cout, act, r.c.training, r.e.st, bn_mask(w, act));
+  return bn_backward(r.c.dtype, dy, w.z, y, w.mean, w.invstd, r.P(c.g), r.P(c.b), dz, dres, param_grads ? r.G(c.g) : nullptr,
+                     param_grads ? r.G(c.b) : nullptr, r.acc, bnws, M, c.Cout, act, r.c.training, r.e.st, bn_mask(w, act));
 }
 
 extern "C" {
@@ -410,7 +411,7 @@ int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* 
   const int B = c.batch, D = c.out_dim, acc = r.acc;
   // Frozen parameter groups (see mmsa_bert_bwd_cb): parameter-table entries are 3 for the stem (conv, BN weight, BN bias),
   // 9 (+3 with a downsample branch) per bottleneck, 2 for the projection. A wholly frozen bottleneck skips its weight-gradient
-  // GEMMs (its BatchNorm backward still runs: the data gradient passes through it); the backward stops below the lowest
+  // GEMMs and writes no BatchNorm gradients (its BatchNorm backward still runs for the data gradient); the backward stops below the lowest
   // trainable group.
   const int nb = (int)L.blocks.size();
   std::vector<int> first(nb + 1);
@@ -452,20 +453,20 @@ int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* 
     BlockWs& bw = ws.blocks[i];
     const void* xin = i == 0 ? ws.pool : ws.blocks[i - 1].c3.y;
     // out = relu(bn3(z3) + idn): dz3 -> t1, masked gradient of the identity branch -> t2
-    RET_IF(bn_bwd(r, bd.c3, bw.c3, dOut, bw.c3.y, t1, t2, MMSA_ACT_RELU, ws.bnws));
+    RET_IF(bn_bwd(r, bd.c3, bw.c3, dOut, bw.c3.y, t1, t2, MMSA_ACT_RELU, ws.bnws, wg));
     if (wg) RET_IF(conv_wgrad(r, bd.c3, t1, bw.c2.y, r.G(bd.c3.w), acc));
     RET_IF(conv_dgrad(r, bd.c3, t1, t3, nullptr));                                   // dy2 -> t3
-    RET_IF(bn_bwd(r, bd.c2, bw.c2, t3, nullptr, t1, nullptr, MMSA_ACT_RELU, ws.bnws));  // dz2 -> t1
+    RET_IF(bn_bwd(r, bd.c2, bw.c2, t3, nullptr, t1, nullptr, MMSA_ACT_RELU, ws.bnws, wg));  // dz2 -> t1
     if (wg) RET_IF(conv_wgrad(r, bd.c2, t1, bw.c1.y, r.G(bd.c2.w), acc));
     RET_IF(conv_dgrad(r, bd.c2, t1, t3, nullptr));                                   // dy1 -> t3
-    RET_IF(bn_bwd(r, bd.c1, bw.c1, t3, nullptr, t1, nullptr, MMSA_ACT_RELU, ws.bnws));  // dz1 -> t1
+    RET_IF(bn_bwd(r, bd.c1, bw.c1, t3, nullptr, t1, nullptr, MMSA_ACT_RELU, ws.bnws, wg));  // dz1 -> t1
     if (const char* dbg = getenv("MMSA_RESNET_BWD_STOP_BLOCK")) {  // diagnostic: leave t3 = dy1, t1 = dz1 of block i intact
       if (atoi(dbg) == i) return MMSA_OK;
     }
     if (wg) RET_IF(conv_wgrad(r, bd.c1, t1, xin, r.G(bd.c1.w), acc));
     const void* skip = t2;  // identity block: the skip gradient is added to conv1's data gradient
     if (bd.has_ds) {
-      RET_IF(bn_bwd(r, bd.ds, bw.ds, t2, nullptr, t3, nullptr, MMSA_ACT_NONE, ws.bnws));  // dzd -> t3
+      RET_IF(bn_bwd(r, bd.ds, bw.ds, t2, nullptr, t3, nullptr, MMSA_ACT_NONE, ws.bnws, wg));  // dzd -> t3
       if (wg) RET_IF(conv_wgrad(r, bd.ds, t3, xin, r.G(bd.ds.w), acc));
       if (!last_needed) {
         RET_IF(conv_dgrad(r, bd.ds, t3, dOut, nullptr));  // dOut is free: holds the projected-skip data gradient

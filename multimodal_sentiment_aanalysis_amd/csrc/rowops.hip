@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void partial_finalize_multi_kernel(const float
   for (int k = 0; k < 16; ++k) t += red[k][c];
   const int q = jj / n, j = jj - q * n;
   float* out = q == 0 ? out0 : (q == 1 ? out1 : out2);
+  if (!out) return;  // a frozen parameter: its gradient is not produced (engine backwards, N2)
   out[j] = accumulate ? out[j] + t : t;
 }
 
@@ -290,7 +291,8 @@ int layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, c
     LN_DISPATCH(layernorm_bwd_kernel, float, H, dim3(grid), dim3(64 * nw), lds, st, (const float*)dy, (const float*)x, mean,
                 rstd, gamma, (float*)dx, ws, M, H, nq);
   MMSA_CHECK_LAUNCH();
-  // partial layout is [blk][nq][H]: one launch finalizes every output
+  if (!dgamma && !dbeta && !dxsum) return MMSA_OK;  // wholly frozen layer: only dx was wanted
+  // partial layout is [blk][nq][H]: one launch finalizes every output (null = that parameter is frozen)
   hipLaunchKernelGGL(partial_finalize_multi_kernel, dim3(cdiv(nq * H, 16)), dim3(256), 0, st, (const float*)ws, grid, nq, H,
                      dgamma, dbeta, dxsum, accumulate);
   MMSA_CHECK_LAUNCH();

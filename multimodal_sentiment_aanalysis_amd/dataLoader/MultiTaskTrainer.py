@@ -56,6 +56,7 @@ class MultiTaskTrainer:
         self.criterion = {"arousal": CrossEntropyLoss(), "valence": CrossEntropyLoss()}
         self.metrics = {split: {k: [] for k in _KEYS} for split in ("train", "test", "val")}
         self.best_val_loss, self.patience, self.counter = float("inf"), 5, 0
+        self.clip_norms = None  # a list: receives every batch's total gradient norm (a device scalar; what clip_grad_norm_ returns)
 
     # ---- helpers
     def _compute_metrics(self, outputs, labels):
@@ -73,10 +74,10 @@ class MultiTaskTrainer:
             for p in getattr(self.model, name).parameters():
                 p.requires_grad = True
         state = self._flat_state()
-        if state is not None:  # HIP kernels over the phase's sub-ranges (norm over every trainable module, step on opt_on)
+        if state is not None:  # HIP kernels over sub-ranges: AdamW on opt_on, clip over every parameter that holds a gradient
             trainable = [getattr(self.model, name) for name in unfreeze]
             owned = trainable if opt_on is None else [getattr(self.model, name) for name in opt_on]
-            opt = PhaseOptimizer(state, owned, trainable, lr=1e-4, weight_decay=1e-4, max_norm=1.0)
+            opt = PhaseOptimizer(state, owned, self.model, lr=1e-4, weight_decay=1e-4, max_norm=1.0)
             sched = Plateau(opt, patience=patience, factor=factor)
         else:
             if opt_on is None:
@@ -160,8 +161,11 @@ class MultiTaskTrainer:
                 loss = c_loss = {"c1": c1, "c2": c2, "c3": c3}[objective]
             loss.backward()
             if not isinstance(opt, PhaseOptimizer):  # (the HIP optimizer's step() is clip + AdamW in one)
-                torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.requires_grad], 1.0)
+                # every parameter that holds a gradient — also stale ones of modules frozen in this phase (MultiTaskTrainer.py:205)
+                total_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
             opt.step()
+            if self.clip_norms is not None:
+                self.clip_norms.append(opt.adamw.norm_out[0].clone() if isinstance(opt, PhaseOptimizer) else total_norm.detach())
             self._add(total, labels[0].shape[0], (a_out, v_out), labels, loss, a_loss, v_loss, c_loss)
         return self._record("train", total, len(self.train_loader.dataset))
 

@@ -164,9 +164,18 @@ class EngineModule(nn.Module):
         if len(stale) == trainable and trainable == len(self._specs):
             self._attach_grads(zero=True)  # the usual case (optimizer over everything): one memset of the flat buffer
             return
+        # a subset: zero the merged ranges (a phase optimizer owning a whole encoder = one memset, not one per tensor; the
+        # 64-element alignment padding between tensors holds zeros anyway)
+        runs = []
         for p, off, shape in stale:
-            self._flat_g[off:off + math.prod(shape)].zero_()
+            n = (math.prod(shape) + 63) // 64 * 64
+            if runs and runs[-1][0] + runs[-1][1] == off:
+                runs[-1][1] += n
+            else:
+                runs.append([off, n])
             p.grad = self._view(self._flat_g, off, shape)
+        for off, n in runs:
+            self._flat_g[off:min(off + n, self._numel)].zero_()
 
     def _acc_flag(self):
         if self._overwrite_next:

@@ -148,8 +148,21 @@ class FlatAdamW:
         self.norm_ws = torch.empty(_lib.load().mmsa_grad_norm_ws_bytes(), dtype=torch.uint8, device=dev)
         # [total norm, clip coefficient | -1 = skipped, 1 - beta1^t, sqrt(1 - beta2^t)] (t = applied steps, this one included)
         self.norm_out = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._set_norm_arrays()
+
+    def _set_norm_arrays(self):
+        if len(self.norm_ranges) > 256:
+            raise _lib.MmsaError(f"{len(self.norm_ranges)} disjoint gradient ranges in one clip norm (limit 256)")
         self._offs = (ctypes.c_int64 * len(self.norm_ranges))(*[a for a, _ in self.norm_ranges])
         self._lens = (ctypes.c_int64 * len(self.norm_ranges))(*[n_ for _, n_ in self.norm_ranges])
+
+    def set_ranges(self, ranges, norm_ranges):
+        """Replace the ranges stepped and the ranges the clip norm spans (made a superset of the former): the set of parameters
+        that hold a gradient can change from step to step (PhaseOptimizer). m and v span the whole buffer, so nothing moves."""
+        self.ranges = merge_ranges(ranges)
+        self.norm_ranges = merge_ranges(list(norm_ranges) + self.ranges)
+        self.extra_ranges = subtract_ranges(self.norm_ranges, self.ranges)
+        self._set_norm_arrays()
 
     @property
     def t(self):
@@ -175,12 +188,8 @@ class FlatAdamW:
             for e, _, _ in st.ranges:
                 if not isinstance(e, HeadEngine):
                     e.mark_weights_fresh()  # the whole bf16 working copy was rewritten by this step
-        # (a partial step leaves the engines' version tokens alone: the next forward re-casts the master, which is correct
-        #  for any subset; FlatAdamW bumps the parameters' version counters below so the tokens do change)
-        else:
-            for e, off, n in st.ranges:
-                if any(a < off + n and off < a + ln for a, ln in self.ranges):
-                    e._wt_token = None
+        # (a partial step needs nothing: the kernel refreshed the bf16 working copy of exactly the ranges it stepped, the rest
+        #  of the master did not change, and the engines' version tokens still describe it)
 
 
 def subtract_ranges(a, b):
@@ -199,46 +208,107 @@ def subtract_ranges(a, b):
     return out
 
 
-def module_ranges(state, modules):
-    """Flat-buffer ranges [(offset, length)] of every parameter of `modules`, padded to the 64-element alignment the tables use
-    (the padding holds zeros in w, g, m and v and stays zero under AdamW), merged."""
+def param_ranges(state, params):
+    """Flat-buffer ranges [(offset, length)] of the given parameters (those that live in the flat buffers), padded to the
+    64-element alignment the tables use (the padding holds zeros in w, g, m and v and stays zero under AdamW), merged."""
     base = state.flat_w.data_ptr()
+    total = state.flat_w.numel()
     out = []
     seen = set()
-    for m in modules:
-        for p in m.parameters():
-            if id(p) in seen:
-                continue
-            seen.add(id(p))
-            off = (p.data_ptr() - base) // 4
-            if 0 <= off < state.flat_w.numel():
-                out.append((off, min((p.numel() + 63) // 64 * 64, state.flat_w.numel() - off)))
+    for p in params:
+        if id(p) in seen:
+            continue
+        seen.add(id(p))
+        off = (p.data_ptr() - base) // 4
+        if 0 <= off < total:
+            out.append((off, min((p.numel() + 63) // 64 * 64, total - off)))
     return merge_ranges(out)
+
+
+def module_ranges(state, modules):
+    """param_ranges of every parameter of `modules`."""
+    return param_ranges(state, [p for m in modules for p in m.parameters()])
 
 
 class PhaseOptimizer:
     """What a curriculum phase of the reference's MultiTaskTrainer builds with torch (`optim.AdamW(params, lr=1e-4,
-    weight_decay=1e-4)` + `clip_grad_norm_(model.parameters(), 1.0)`, MultiTaskTrainer.py:55-177,179-467), on the HIP kernels
-    over sub-ranges of the flat buffers: `step()` = clip over `clip_modules` (every trainable parameter) + AdamW on
-    `opt_modules`; `zero_grad()` clears the optimizer's own gradients only — the reference's phase 3 never zeroes the
-    gradients of the modules it unfreezes but does not optimize, they accumulate from batch to batch and enter every norm.
-    `param_groups[0]["lr"]` is live, so a plateau scheduler can drive it."""
+    weight_decay=1e-4)` + `clip_grad_norm_(self.model.parameters(), 1.0)`, MultiTaskTrainer.py:55-177,179-467), on the HIP
+    kernels over sub-ranges of the flat buffers: `step()` = clip + AdamW on `opt_modules`.
 
-    def __init__(self, state, opt_modules, clip_modules, lr=1e-4, weight_decay=1e-4, max_norm=1.0):
-        self.state = state
-        self.opt_ranges = module_ranges(state, opt_modules)
-        self.clip_ranges = module_ranges(state, clip_modules)
+    The clip is the reference's: over EVERY parameter of the model whose `.grad` is not None at that moment
+    (`clip_grad_norm_(self.model.parameters(), ...)`, MultiTaskTrainer.py:205,261,317,378,439) — the trainable modules of the
+    phase AND anything frozen now that still holds a gradient from an earlier phase (arousal_head and the encoders while
+    phase 3 runs, eeg_net while the eye phase runs): those stale gradients enter every norm and are rescaled in place by every
+    clip. `zero_grad()` drops the optimizer's own gradients only (torch's set_to_none: the next backward re-creates them from
+    zero) — the reference's phase 3 never zeroes the modules it unfreezes but does not optimize, so they keep accumulating.
+    `param_groups[0]["lr"]` is live, so a plateau scheduler can drive it. `norm_history` (when a list) receives a clone of
+    the device-side [norm, clip coefficient, ...] of every step (tests compare it with the reference's return values)."""
+
+    def __init__(self, state, opt_modules, model, lr=1e-4, weight_decay=1e-4, max_norm=1.0):
+        self.state, self.model = state, model
+        self.opt_params = [p for m in opt_modules for p in m.parameters()]
+        self.opt_ranges = param_ranges(state, self.opt_params)
         self.param_groups = [{"lr": lr}]
-        self.adamw = FlatAdamW(state, lr=lr, weight_decay=weight_decay, max_norm=max_norm, ranges=self.opt_ranges,
-                               norm_ranges=self.clip_ranges)
+        self.adamw = FlatAdamW(state, lr=lr, weight_decay=weight_decay, max_norm=max_norm, ranges=self.opt_ranges)
+        self.norm_history = None
+        self._live_key = None
 
     def zero_grad(self):
-        for a, n in self.opt_ranges:
-            self.state.flat_g[a:a + n].zero_()
+        for p in self.opt_params:
+            p.grad = None
+
+    def live_ranges(self):
+        """Ranges of every parameter that holds a gradient now (`p.grad is not None`): what clip_grad_norm_ sees; the
+        optimizer's own parameters among them are what AdamW steps (torch skips a parameter whose .grad is None)."""
+        live = [p for p in self.model.parameters() if p.grad is not None]
+        key = tuple(id(p) for p in live)
+        if key != self._live_key:
+            self._live_key = key
+            ids = set(key)
+            self.adamw.set_ranges(param_ranges(self.state, [p for p in self.opt_params if id(p) in ids]),
+                                  param_ranges(self.state, live))
+        return self.adamw.norm_ranges
 
     def step(self):
         self.adamw.lr = self.param_groups[0]["lr"]
+        self.live_ranges()
+        if not self.adamw.norm_ranges:
+            return
         self.adamw.step()
+        if self.norm_history is not None:
+            self.norm_history.append(self.adamw.norm_out.clone())
+
+
+class FlatAdam:
+    """`optim.Adam(list(encoder.parameters()) + list(projection_head.parameters()), lr=lr)` / `optim.Adam(classifier.parameters(),
+    lr=lr)` of the reference's two-stage pipeline (train.py:52,94) on the HIP optimizer kernel: Adam is AdamW with zero decay, and
+    without a clip the coefficient is 1 (max_norm = inf). One FlatAdamW per flat parameter state (modules that were materialized
+    separately — encoder, projection head, classifier — own separate flat buffers); `zero_grad()` is torch's set_to_none."""
+
+    def __init__(self, modules, lr=1e-3, device=None, betas=(0.9, 0.999), eps=1e-8):
+        self.param_groups = [{"lr": lr}]
+        self.parts = []
+        for m in modules:
+            st = getattr(m, "_flat_state", None)
+            if st is None or not st.valid():
+                dev = torch.device(device) if device is not None else next(m.parameters()).device
+                st = materialize(m, dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device()))
+            params = list(m.parameters())
+            ranges = param_ranges(st, params)
+            if sum(n for _, n in ranges) < sum(p.numel() for p in params):
+                raise _lib.MmsaError("FlatAdam: a parameter lives outside the module's flat buffers")
+            self.parts.append((params, FlatAdamW(st, lr, 0.0, betas, eps, max_norm=float("inf"), ranges=ranges)))
+
+    def zero_grad(self):
+        for params, _ in self.parts:
+            for p in params:
+                p.grad = None
+
+    def step(self):
+        for params, opt in self.parts:
+            if any(p.grad is not None for p in params):  # (torch.optim.Adam skips parameters without a gradient)
+                opt.lr = self.param_groups[0]["lr"]
+                opt.step()
 
 
 class Plateau:
@@ -279,10 +349,19 @@ class FusedTrainStep:
     """model: MultimodalTransformerModel (Trainer contract). One call = one optimizer step."""
 
     def __init__(self, model, device, precision="bf16", lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
-                 max_norm=1.0, bucket_bytes=64 << 20, two_streams=False):
+                 max_norm=1.0, bucket_bytes=64 << 20, two_streams=False, min_bucket_bytes=16 << 20, train_mode=True):
+        """train_mode=False: the forward runs in eval mode (BatchNorm on its running statistics, no dropout) while gradients
+        and the optimizer step are still taken — the configuration SURVEY.md section 8(e) prescribes for checking that N ranks x
+        B/N samples reproduce one rank x B samples (batch statistics would differ between the two by construction)."""
+        self.train_mode = bool(train_mode)
         self.model, self.device = model, torch.device(device)
         self.state = materialize(model, self.device, precision)
-        self.opt = FlatAdamW(self.state, lr, weight_decay, betas, eps, max_norm)
+        # the optimizer owns the TRAINABLE parameters (Trainer.py:19-21 builds AdamW over model.parameters(); a frozen
+        # encoder — train.py:90-92 — must not even decay): ranges of every requires_grad parameter; all of them = one range
+        params = list(model.parameters())
+        trainable = [p for p in params if p.requires_grad]
+        ranges = None if len(trainable) == len(params) else param_ranges(self.state, trainable)
+        self.opt = FlatAdamW(self.state, lr, weight_decay, betas, eps, max_norm, ranges=ranges)
         self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # (No CU reservation for the collective by default. A workgroup of the persistent GEMM fills its CU, so RCCL's blocks
@@ -292,7 +371,8 @@ class FusedTrainStep:
         # gradient payload of the all-reduce: MMSA_GRAD_PAYLOAD=fp32 | bf16 (default fp32: bit-identical sums on every rank in
         # rank order independent precision; bf16 halves the bytes on xGMI — DESIGN.md §6)
         payload = os.environ.get("MMSA_GRAD_PAYLOAD", "fp32")
-        self.reducer = GradReducer(self.state.flat_g, bucket_bytes, payload=payload) if self.world > 1 else None
+        self.reducer = (GradReducer(self.state.flat_g, bucket_bytes, payload=payload, min_bucket_bytes=min_bucket_bytes)
+                        if self.world > 1 else None)
         if self.world > 1:  # identical replicas: parameters and BN buffers from rank 0
             dist.broadcast(self.state.flat_w, 0)
             dist.broadcast(self.state.flat_bn, 0)
@@ -329,7 +409,7 @@ class FusedTrainStep:
             raise _lib.MmsaError("flat parameter buffers were invalidated (model.to()/.float() after FusedTrainStep)")
         L = _lib.load()
         model = self.model
-        model.train()
+        model.train(self.train_mode)
         if self.reducer is not None:
             self.reducer.begin_step()
         for e, _, _ in self.state.ranges:

@@ -3,11 +3,21 @@
 
 Stage 2 (the CE path: frozen encoder -> Classifier -> CE_a + CE_v, Adam lr as given) and stage 1's supervised-contrastive
 loss on the [2B, 2B] similarity matrix (train.py:16-40) run on the HIP modules / kernels.
+The optimizer of both stages (`optim.Adam(..., lr=lr)`, train.py:52,94) is the HIP AdamW kernel with zero decay and no clip
+(fused.FlatAdam) when the modules live on a GPU; `hip_optimizer=False` keeps torch.optim.Adam on the same parameter views.
+Per-batch `.item()` syncs of the reference's loop are replaced by a device-side sum read once per epoch.
 This file is host code, like the reference's."""
 import torch
 import torch.optim as optim
 
 from .engine import CrossEntropyLoss, nt_xent_loss, supcon_loss  # noqa: F401  (nt_xent_loss: ME-MHACL/train.py:47-66)
+from .fused import FlatAdam
+
+
+def _adam(modules, lr, device, hip_optimizer):
+    if hip_optimizer and torch.device(device).type == "cuda":
+        return FlatAdam(modules, lr=lr, device=device)
+    return optim.Adam([p for m in modules for p in m.parameters()], lr=lr)
 
 
 def contrastive_loss(z1, z2, labels, temperature=0.1):
@@ -15,13 +25,14 @@ def contrastive_loss(z1, z2, labels, temperature=0.1):
     return supcon_loss(z1, z2, labels, temperature)
 
 
-def contrastive_pretrain_trainer(encoder, projection_head, contrastive_loader, num_epochs=20, lr=1e-3, device=None):
+def contrastive_pretrain_trainer(encoder, projection_head, contrastive_loader, num_epochs=20, lr=1e-3, device=None,
+                                 hip_optimizer=True):
     device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
     encoder.to(device); projection_head.to(device)
-    optimizer = optim.Adam(list(encoder.parameters()) + list(projection_head.parameters()), lr=lr)
+    optimizer = _adam([encoder, projection_head], lr, device, hip_optimizer)
     for epoch in range(num_epochs):
         encoder.train(); projection_head.train()
-        total = 0.0
+        total = torch.zeros((), device=device)
         for batch in contrastive_loader:
             a1, b1, c1, a2, b2, c2, labels = [t.to(device) for t in batch]
             z1, z2 = projection_head(encoder(a1, b1, c1)), projection_head(encoder(a2, b2, c2))
@@ -29,21 +40,21 @@ def contrastive_pretrain_trainer(encoder, projection_head, contrastive_loader, n
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()
-            total += loss.item()
-        print(f"Epoch [{epoch + 1}] Contrastive Loss: {total / max(len(contrastive_loader), 1):.4f}")
+            total += loss.detach().reshape(())
+        print(f"Epoch [{epoch + 1}] Contrastive Loss: {total.item() / max(len(contrastive_loader), 1):.4f}")
     return encoder, projection_head
 
 
-def finetune_trainer(encoder, classifier, train_loader, test_loader, num_epochs=20, lr=1e-3, device=None):
+def finetune_trainer(encoder, classifier, train_loader, test_loader, num_epochs=20, lr=1e-3, device=None, hip_optimizer=True):
     device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
     encoder.to(device); classifier.to(device)
     for p in encoder.parameters():
         p.requires_grad = False
     criterion = CrossEntropyLoss()
-    optimizer = optim.Adam(classifier.parameters(), lr=lr)
+    optimizer = _adam([classifier], lr, device, hip_optimizer)
     for epoch in range(num_epochs):
         classifier.train()
-        total = 0.0
+        total = torch.zeros((), device=device)
         for x1, x2, x3, arousal, valence in train_loader:
             x1, x2, x3 = x1.to(device), x2.to(device), x3.to(device)
             arousal, valence = arousal.to(device), valence.to(device)
@@ -53,15 +64,17 @@ def finetune_trainer(encoder, classifier, train_loader, test_loader, num_epochs=
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()
-            total += loss.item()
-        print(f"Epoch [{epoch + 1}] Finetune Loss: {total / max(len(train_loader), 1):.4f}")
+            total += loss.detach().reshape(())
+        print(f"Epoch [{epoch + 1}] Finetune Loss: {total.item() / max(len(train_loader), 1):.4f}")
         classifier.eval()
-        ca = cv = n = 0
+        hits = torch.zeros(2, dtype=torch.long, device=device)
+        n = 0
         with torch.no_grad():
             for x1, x2, x3, arousal, valence in test_loader:
                 out_a, out_v = classifier(encoder(x1.to(device), x2.to(device), x3.to(device)))
-                ca += (out_a.argmax(1).cpu() == arousal).sum().item()
-                cv += (out_v.argmax(1).cpu() == valence).sum().item()
+                hits[0] += (out_a.argmax(1) == arousal.to(device)).sum()
+                hits[1] += (out_v.argmax(1) == valence.to(device)).sum()
                 n += arousal.size(0)
+        ca, cv = hits.tolist()
         print(f"Test Accuracy - Arousal: {ca / max(n, 1):.4f}, Valence: {cv / max(n, 1):.4f}")
     return classifier

@@ -25,7 +25,7 @@ def _ln(x, w, b, eps):
 def bert_forward(sd, p, input_ids, attention_mask, cfg, pol=FP32):
     """Returns (last_hidden [B,S,H], pooled [B,H]). `p` is the name prefix of the BertModel parameters (HF names).
     `pol.q` marks where the bf16 HIP path stores a rounded tensor."""
-    q, qw = pol.q, pol.qw
+    q, qw, lin = pol.q, pol.qw, pol.linear  # lin: the four Linears per layer that configs[4] runs on fp8 operands
     B, S = input_ids.shape
     H, A, eps = cfg["hidden"], cfg["heads"], cfg["ln_eps"]
     hd = H // A
@@ -42,18 +42,18 @@ def bert_forward(sd, p, input_ids, attention_mask, cfg, pol=FP32):
                           W(lp + "attention.self.value.weight")], 0)
         bqkv = torch.cat([sd[p + lp + "attention.self.query.bias"], sd[p + lp + "attention.self.key.bias"],
                           sd[p + lp + "attention.self.value.bias"]], 0)
-        qkv = q(x @ Wqkv.t() + bqkv).view(B, S, 3, A, hd)
+        qkv = q(lin(x, Wqkv) + bqkv).view(B, S, 3, A, hd)
         qh, kh, vh = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
         scores = qh @ kh.transpose(-1, -2) * (1.0 / math.sqrt(hd))
         if keep is not None:
             scores = scores.masked_fill(~keep[:, None, None, :], -3.0e38)
         probs = q(torch.softmax(scores, dim=-1))
         ctx = q((probs @ vh).transpose(1, 2).reshape(B * S, H))
-        s1 = q(ctx @ W(lp + "attention.output.dense.weight").t() + sd[p + lp + "attention.output.dense.bias"] + x)
+        s1 = q(lin(ctx, W(lp + "attention.output.dense.weight")) + sd[p + lp + "attention.output.dense.bias"] + x)
         h1 = q(_ln(s1, sd[p + lp + "attention.output.LayerNorm.weight"], sd[p + lp + "attention.output.LayerNorm.bias"], eps))
-        pre = h1 @ W(lp + "intermediate.dense.weight").t() + sd[p + lp + "intermediate.dense.bias"]
+        pre = lin(h1, W(lp + "intermediate.dense.weight")) + sd[p + lp + "intermediate.dense.bias"]
         act = q(gelu(pre))
-        s2 = q(act @ W(lp + "output.dense.weight").t() + sd[p + lp + "output.dense.bias"] + h1)
+        s2 = q(lin(act, W(lp + "output.dense.weight")) + sd[p + lp + "output.dense.bias"] + h1)
         x = q(_ln(s2, sd[p + lp + "output.LayerNorm.weight"], sd[p + lp + "output.LayerNorm.bias"], eps))
     hidden = x.view(B, S, H)
     pooled = q(torch.tanh(hidden[:, 0] @ W("pooler.dense.weight").t() + sd[p + "pooler.dense.bias"]))

@@ -15,6 +15,12 @@ Three refinements over round 1:
     rounding (two correct bf16 forwards differ by 1-ulp flips that decorrelate within a few layers), and a wrong
     backward kernel cannot hide behind a loose tolerance.
   * `trace={}`: collects every named activation (for tests that look at intermediate tensors).
+  * `fp8="tensor"` (BF16G_FP8, BASELINE.json configs[4]): the text encoder's four forward Linears per layer take e4m3 operands —
+    activation and weight are each scaled by 448 / amax (amax over the whole bf16-stored tensor: "current" per-tensor scaling),
+    rounded to OCP e4m3 (torch.float8_e4m3fn = round-to-nearest-even, what v_cvt_pk_fp8_f32 does), multiplied exactly and
+    rescaled: csrc/gemm_fp8.hip restated. The backward is the bf16 one (straight-through: gradients use the UNQUANTIZED bf16
+    operands, as the device's backward does). `fp8="row"`: one scale per activation ROW (token) and per weight ROW (output
+    feature) — the scaling the LayerNorm-fused quantizer produces.
 """
 import torch
 
@@ -57,10 +63,41 @@ class _Force(torch.autograd.Function):
         return (_rne(g) if ctx.round_grads else g), None, None
 
 
+FP8_MAX = 448.0
+
+
+def e4m3_quantize(x, per_row):
+    """(q, scale): q = e4m3(x * 448 / amax) as fp32 values, scale = amax / 448 (amax over the tensor, or over each row);
+    the expressions of csrc/gemm_fp8.hip::fp8_quant_kernel (inv = 448 / amax in fp32, clamp, RNE conversion)."""
+    a = x.abs().amax(dim=-1, keepdim=True) if per_row else x.abs().amax()
+    a = a.clamp_min(1e-20).to(torch.float32)
+    inv = torch.tensor(FP8_MAX, dtype=torch.float32) / a
+    f = (x.to(torch.float32) * inv).clamp(-FP8_MAX, FP8_MAX)
+    return f.to(torch.float8_e4m3fn).to(torch.float32), a * torch.tensor(1.0 / FP8_MAX, dtype=torch.float32)
+
+
+class _Fp8Linear(torch.autograd.Function):
+    """forward: (q_x q_w^T) * scale_x * scale_w; backward: straight-through with the unquantized operands."""
+
+    @staticmethod
+    def forward(ctx, x, w, per_row):
+        qx, sx = e4m3_quantize(x, per_row)
+        qw, sw = e4m3_quantize(w, per_row)
+        ctx.save_for_backward(x, w)
+        y = qx @ qw.t()
+        return y * sx * (sw.t() if per_row else sw)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        return g @ w, g.t() @ x, None
+
+
 class Policy:
-    def __init__(self, storage="fp32", round_grads=False, forced=None, trace=None):
-        assert storage in ("fp32", "bf16")
-        self.storage, self.round_grads, self.forced, self.trace = storage, round_grads, forced, trace
+    def __init__(self, storage="fp32", round_grads=False, forced=None, trace=None, fp8=None):
+        assert storage in ("fp32", "bf16") and fp8 in (None, "tensor", "row")
+        assert fp8 is None or storage == "bf16"
+        self.storage, self.round_grads, self.forced, self.trace, self.fp8 = storage, round_grads, forced, trace, fp8
         self.local_err = {}  # forcing: relative L2 distance of each forced tensor from the value computed from its forced inputs
 
     def q(self, x, name=None):
@@ -76,6 +113,13 @@ class Policy:
             self.trace[name] = x
         return x
 
+    def linear(self, x, w):
+        """x [M,K] (a stored activation) times w [N,K]^T (a working-copy weight, already through `qw`) for the Linears that the
+        fp8 configuration quantizes; plain product otherwise."""
+        if self.fp8 is None:
+            return x @ w.t()
+        return _Fp8Linear.apply(x, w, self.fp8 == "row")
+
     def qw(self, w):
         """The working copy of a WEIGHT in the storage type: forward rounding only (weight gradients are fp32)."""
         return w if self.storage == "fp32" else _RoundBF16.apply(w)
@@ -84,3 +128,4 @@ class Policy:
 FP32 = Policy("fp32")
 BF16 = Policy("bf16")
 BF16G = Policy("bf16", round_grads=True)
+BF16G_FP8 = Policy("bf16", round_grads=True, fp8="tensor")

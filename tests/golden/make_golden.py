@@ -423,11 +423,27 @@ def gen_multitask_phases():
     train, test = DataLoader(ds, batch_size=bs, shuffle=False), DataLoader(ds, batch_size=bs, shuffle=False)
     arrays = {"w0." + k: v.clone() for k, v in m.state_dict().items()}
     tr = ref_mtt.MultiTaskTrainer(m, train, test, device="cpu")
-    r2 = tr.train_epoch_phase2(1)
-    arrays.update({"w_p2." + k: v.clone() for k, v in m.state_dict().items()})
-    e2 = tr.evaluate()
-    m.train()
-    r3 = tr.train_epoch_phase3(1)
+    # record what the reference's own `torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)` calls return (the total
+    # norm over every parameter that holds a gradient — in phase 3 that includes the STALE gradient the frozen arousal head
+    # kept from phase 2): the real function runs, wrapped only to log its return value
+    real_clip, norms = torch.nn.utils.clip_grad_norm_, []
+
+    def logging_clip(*a, **k):
+        total = real_clip(*a, **k)
+        norms.append(float(total))
+        return total
+
+    torch.nn.utils.clip_grad_norm_ = logging_clip
+    try:
+        r2 = tr.train_epoch_phase2(1)
+        arrays.update({"w_p2." + k: v.clone() for k, v in m.state_dict().items()})
+        e2 = tr.evaluate()
+        m.train()
+        r3 = tr.train_epoch_phase3(1)
+    finally:
+        torch.nn.utils.clip_grad_norm_ = real_clip
+    arrays["clip_norms"] = torch.tensor(norms, dtype=torch.float64)  # 2 batches of phase 2, then 2 of phase 3
+    print("clip norms per batch:", norms)
     arrays.update({"w_p3." + k: v.clone() for k, v in m.state_dict().items()})
     e3 = tr.evaluate()
     for tag, r in (("train_p2", r2), ("eval_p2", e2), ("train_p3", r3), ("eval_p3", e3)):

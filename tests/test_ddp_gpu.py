@@ -1,0 +1,163 @@
+"""GPU, two REAL ranks on one MI355X (gloo process group, both ranks on cuda:0): the data-parallel step of the HIP engines —
+FusedTrainStep with the callback-driven bucket path (mmsa_bert_bwd_cb / mmsa_resnet_bwd_cb -> GradReducer.add on a side HIP
+stream). SURVEY.md section 8(e)'s correctness checks, the only multi-GPU evidence obtainable without an 8-GPU node:
+
+  * reduced gradients bit-identical across ranks;
+  * 2 ranks x B=8 reproduce 1 rank x B=16 (BatchNorm on running statistics, dropout off): loss, reduced gradient, weights;
+  * >= 5 collectives are issued before the last chunk of backward kernels is even enqueued (overlap by construction);
+  * bf16 gradient payload (MMSA_GRAD_PAYLOAD=bf16): bounded, replicas still bit-identical to each other;
+  * a partially frozen encoder (N2 / train.py:90-92): frozen tensors bit-unchanged (no decay), replicas stay equal.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(seed, freeze):
+    import multimodal_sentiment_aanalysis_amd as mm
+    from util import MINI_BERT, MINI_RESNET
+    torch.manual_seed(seed)
+    model = mm.MultimodalTransformerModel(bert_config=MINI_BERT, resnet_config=dict(blocks=(2, 1, 1, 1), widths=(64, 64, 128, 128)),
+                                          dropout=0.0)
+    with torch.no_grad():  # non-trivial running statistics (the forward runs BatchNorm in eval mode)
+        for n, b in model.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn_like(b))
+            if n.endswith("running_var"):
+                b.copy_(1.0 + 0.2 * torch.rand_like(b))
+    frozen = []
+    if freeze:
+        for n, p in model.named_parameters():
+            if ".encoder.layer.0." in n or ".layer1.0." in n or n.startswith("cross_attn_t2i."):
+                p.requires_grad = False
+                frozen.append(n)
+    return model, frozen
+
+
+def _batch(dev):
+    from util import MINI_BERT, synth_batch
+    return synth_batch(16, 32, 64, 64, MINI_BERT["vocab"], seed=11, dev=dev)
+
+
+def _run_step(model, dev, sl, **kw):
+    from multimodal_sentiment_aanalysis_amd.fused import FusedTrainStep
+    step = FusedTrainStep(model, dev, precision="fp32", train_mode=False, min_bucket_bytes=64 << 10, **kw)
+    w0 = step.state.flat_w.clone()
+    image, ids, mask, labels = _batch(dev)
+    counts = []
+    if step.reducer is not None:
+        real_add = step.reducer.add
+
+        def add(start, length):  # how many collectives were already issued when this range is announced
+            counts.append(len(step.reducer.issued))
+            real_add(start, length)
+
+        step.reducer.add = add
+    loss, logits = step.step(image[sl], ids[sl], mask[sl], labels[sl])
+    torch.cuda.synchronize()
+    return step, w0, loss.detach().cpu(), counts
+
+
+def _worker(rank, world, port, out, case):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if case == "bf16":
+        os.environ["MMSA_GRAD_PAYLOAD"] = "bf16"
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model, frozen = _build(seed=rank, freeze=(case == "frozen"))  # rank 1 starts from OTHER weights: rank 0's are broadcast
+    step, w0, loss, counts = _run_step(model, dev, slice(rank * 8, rank * 8 + 8))
+    names = {n: (p.data_ptr() - step.state.flat_w.data_ptr()) // 4 for n, p in model.named_parameters()
+             if 0 <= (p.data_ptr() - step.state.flat_w.data_ptr()) // 4 < step.state.flat_w.numel()}
+    torch.save(dict(g=step.state.flat_g.cpu(), w=step.state.flat_w.cpu(), w0=w0.cpu(), loss=loss, counts=counts,
+                    issued=list(step.reducer.issued), norm=step.opt.norm_out.cpu(), frozen=frozen, offs=names,
+                    numel={n: p.numel() for n, p in model.named_parameters()}),
+               os.path.join(out, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn(tmp_path, case):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), case), nprocs=2, join=True)
+    return [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=False) for r in range(2)]
+
+
+def _single(dev, freeze=False):
+    model, _ = _build(seed=0, freeze=freeze)
+    step, w0, loss, _ = _run_step(model, dev, slice(0, 16))
+    return dict(g=step.state.flat_g.cpu(), w=step.state.flat_w.cpu(), w0=w0.cpu(), loss=loss, norm=step.opt.norm_out.cpu())
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_step(dev, tmp_path):
+    r0, r1 = _spawn(tmp_path, "fp32")
+    assert torch.equal(r0["w0"], r1["w0"]), "rank 0's parameters were broadcast"
+    assert torch.equal(r0["g"], r1["g"]), "all-reduced gradients must be bit-identical across ranks"
+    assert torch.equal(r0["w"], r1["w"]), "replicas must stay bit-identical after the step"
+    one = _single(dev)
+    assert torch.equal(one["w0"], r0["w0"])
+    # loss: the mean over 16 = the average of the two ranks' means over 8
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - one["loss"]).item() < 1e-5, (r0["loss"], r1["loss"], one["loss"])
+    # reduced gradient (a SUM over ranks; the 1/world average is folded into the norm / AdamW kernels) = full-batch gradient
+    gref = one["g"]
+    err = (0.5 * r0["g"] - gref).abs().max().item() / gref.abs().max().item()
+    assert err < 1e-5, f"reduced gradient vs single-process gradient: {err:.2e}"
+    assert abs(r0["norm"][0] - one["norm"][0]).item() < 1e-5 * one["norm"][0].item()
+    # weights: an AdamW first step moves every element by ~lr whatever its gradient's size, so an element whose gradient is
+    # rounding noise may step the other way: bound 2.2 lr, and all but a sliver of the elements agree to 2e-6
+    diff = (r0["w"] - one["w"]).abs()
+    assert diff.max().item() <= 2.2e-4
+    assert (diff > 2e-6).double().mean().item() < 5e-3
+    # overlap by construction: collectives already issued when the LAST range of the backward is announced
+    assert len(r0["issued"]) >= 6 and r0["counts"][-1] >= 5, (len(r0["issued"]), r0["counts"])
+    covered = torch.zeros(r0["g"].numel(), dtype=torch.int32)
+    for a, n in r0["issued"]:
+        covered[a:a + n] += 1
+    assert int(covered.max()) == 1, "no gradient element is reduced twice"
+
+
+def test_two_ranks_bf16_gradient_payload(dev, tmp_path):
+    r0, r1 = _spawn(tmp_path, "bf16")
+    assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["w"], r1["w"])
+    one = _single(dev)
+    gref = one["g"]
+    rel = ((0.5 * r0["g"] - gref).norm() / gref.norm()).item()
+    assert rel < 2 ** -7, f"bf16 payload: reduced gradient rel-L2 {rel:.2e} (two bf16 roundings per element)"
+
+
+def test_two_ranks_partially_frozen_encoder(dev, tmp_path):
+    r0, r1 = _spawn(tmp_path, "frozen")
+    assert r0["frozen"], "the case froze something"
+    assert torch.equal(r0["w"], r1["w"]), "replicas diverged with a partially frozen encoder"
+    assert torch.equal(r0["g"], r1["g"])
+    moved_frozen, moved_live = [], 0
+    for n, off in r0["offs"].items():
+        k = r0["numel"][n]
+        same = torch.equal(r0["w"][off:off + k], r0["w0"][off:off + k])
+        if n in r0["frozen"]:
+            if not same:
+                moved_frozen.append(n)
+        elif not same:
+            moved_live += 1
+    assert not moved_frozen, f"frozen tensors moved (decay or stale gradient applied): {moved_frozen[:4]}"
+    assert moved_live > 50
+    one = _single(dev, freeze=True)
+    err = (0.5 * r0["g"] - one["g"]).abs().max().item() / one["g"].abs().max().item()
+    assert err < 1e-5, err

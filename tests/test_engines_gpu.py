@@ -103,7 +103,7 @@ def test_resnet_engine(dev, precision, pol, tol_f, tol_g, rcfg, B, HW):
             # 53 train-mode BatchNorms over 8-sample statistics: chaotic under bf16 storage (20 % feature distance between
             # two correct implementations). The full-depth bf16 checks are test_resnet_backward_teacher_forced (tight, at
             # the device's own forward) and test_resnet_engine_full_depth_bf16 (free-running, well conditioned: B = 16).
-            return
+            pytest.skip("full-depth bf16: covered by test_resnet_backward_teacher_forced / test_resnet_engine_full_depth_bf16")
     net = ResNetImageNet(rcfg)
     net.precision = precision
     # non-trivial BN affine so its gradients are exercised
@@ -188,7 +188,10 @@ def _saved_resnet_activations(out, ocfg, shapes):
 
 
 @pytest.mark.parametrize("rcfg,B,HW,tol", [(MINI_RESNET, 4, 96, 2e-2), (RESNET50_NARROW, 16, 96, 4e-2),
-                                           (dict(blocks=(3, 4, 6, 3), widths=(64, 128, 256, 512)), 16, 96, 4e-2)])
+                                           (dict(blocks=(3, 4, 6, 3), widths=(64, 128, 256, 512)), 16, 96, 4e-2),
+                                           # J1 (BASELINE configs[3]): ResNet-101's block structure (a 23-bottleneck stage),
+                                           # 64-wide; the random walk of stored-gradient roundings is 33 blocks long
+                                           (dict(blocks=(3, 4, 23, 3), widths=(64, 64, 64, 64)), 16, 96, 6e-2)])
 def test_resnet_backward_teacher_forced(dev, rcfg, B, HW, tol):
     """THE tight check of the bf16 (MFMA) ResNet backward, at full depth (53 BatchNorms; the last case is ResNet-50 itself).
 
@@ -784,36 +787,90 @@ def test_frozen_groups_skip_kernels_and_keep_gradients(dev, which):
 
 def test_bert_engine_fp8(dev):
     """BASELINE.json configs[4] at the engine level: the text encoder with fp8 (e4m3) operands in its forward Linears (precision
-    "fp8": bf16 storage, per-tensor current scaling, bf16 backward) against the same encoder in bf16. e4m3 keeps 3 mantissa bits:
-    every fp8 GEMM adds ~4-6 % (rms) to its output, so the bound is loose by construction — what it pins is that the fp8 path is
-    wired correctly end to end (scales, epilogues, side outputs feeding the backward) and trains."""
+    "fp8": bf16 storage, per-tensor current scaling, bf16 backward) against the ORACLE under the same policy (oracle/policy.py
+    BF16G_FP8: the same scales, the same e4m3 rounding, exact products, straight-through bf16 backward). The two quantize
+    identical tensors identically, so they differ like two bf16 implementations do (~1e-2), not by e4m3's 2^-4 steps; how far fp8
+    moves the feature from bf16 (the price of the format) is printed beside it."""
+    from oracle.policy import BF16G_FP8
     torch.manual_seed(0)
     cfg = dict(MINI_BERT, hidden=256, heads=4, intermediate=1024)  # K = 256 / 1024: multiples of the fp8 K step (128)
     _, ids, mask, _ = synth_batch(8, 32, 32, 32, cfg["vocab"], seed=5)
-    wgt = torch.randn(8, 256, generator=torch.Generator().manual_seed(9)).to(dev)
-    outs, grads = {}, {}
-    L = _lib.load()
-    for prec in ("bf16", "fp8"):
-        torch.manual_seed(0)
-        net = BertTextNet(cfg)
-        net.precision = prec
-        net.to(dev)
-        L.mmsa_prof_mode(0)
-        L.mmsa_prof_begin(1024)
-        out = net(ids.to(dev), mask.to(dev))
-        torch.cuda.synchronize()
-        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-        L.mmsa_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
-        (out * wgt).sum().backward()
-        outs[prec], grads[prec] = out.detach().float().cpu(), _grads(net)
-        assert torch.isfinite(outs[prec]).all()
-    rel = ((outs["fp8"] - outs["bf16"]).norm() / outs["bf16"].norm()).item()
-    print(f"fp8 vs bf16 text feature: relative L2 {rel:.3e}")
-    assert 1e-4 < rel < 0.25, rel  # > 0: the fp8 kernels really ran; < 0.25: they compute the same function
-    # gradients: the backward is the bf16 one, evaluated at the fp8 forward's (1 % different) activations; per tensor, relative
-    # to its own norm with the usual floor for analytically-zero gradients (the key bias under softmax)
-    _check_grads(grads["fp8"], grads["bf16"], 0.25, "fp8 forward / bf16 backward vs bf16", l2=True)
+    wgt = torch.randn(8, 256, generator=torch.Generator().manual_seed(9))
+    net = BertTextNet(cfg)
+    net.precision = "fp8"
+    sd = cpu_state(net)
 
+    def feat_fn(work, pol):
+        _, pooled = bert_forward(work, "bert.", ids, mask, cfg, pol)
+        return pooled @ pol.qw(work["proj.weight"]).t() + work["proj.bias"]
+
+    ref8, ref16 = feat_fn(sd, BF16G_FP8), feat_fn(sd, BF16G)
+    net.to(dev)
+    out = net(ids.to(dev), mask.to(dev))
+    assert torch.isfinite(out).all()
+    e_oracle = ((out.detach().cpu() - ref8).norm() / ref8.norm()).item()
+    price = ((ref8 - ref16).norm() / ref16.norm()).item()
+    print(f"fp8 engine vs fp8-policy oracle: rel L2 {e_oracle:.3e}; fp8-policy vs bf16-policy oracle (price of e4m3): {price:.3e}")
+    assert price > 5e-3, "the fp8 policy really quantizes"
+    assert e_oracle < 0.35 * price + 5e-3, (e_oracle, price)  # well inside the format's own error: the same function
+    (out * wgt.to(dev)).sum().backward()
+    names = [n for n, _ in net.named_parameters()]
+    ref_g = _oracle_grads(sd, names, lambda w: (feat_fn(w, BF16G_FP8) * wgt).sum())
+    _check_grads(_grads(net), ref_g, 8e-2, "fp8 forward / bf16 backward vs the fp8-policy oracle", l2=True)
+
+
+def test_fp8_linear_propagates_non_finite_inputs(dev):
+    """A NaN / Inf in a quantized Linear's input must reach its output (the amax pass turns the scale into Inf): otherwise the
+    clamp of the e4m3 conversion would launder it into +-448 and the trainer's NaN rule (Trainer.py:74-76) could never fire for
+    a fault upstream of an fp8 GEMM."""
+    from multimodal_sentiment_aanalysis_amd import kernels as K
+    torch.manual_seed(0)
+    x = torch.randn(256, 256, device=dev).bfloat16()
+    w = torch.randn(128, 256, device=dev).bfloat16()
+    wq, sw = K.fp8_quantize(w)
+
+    def linear(xin):
+        xq, sx = K.fp8_quantize(xin)
+        y = torch.empty(256, 128, dtype=torch.bfloat16, device=dev)
+        assert K.gemm_fp8(xq, sx, wq, sw, y) == 0
+        return y.float()
+
+    assert torch.isfinite(linear(x)).all()
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        xb = x.clone()
+        xb[17, 3] = bad
+        assert not torch.isfinite(linear(xb)).all(), f"{bad} was laundered into finite values"
+
+
+@pytest.mark.parametrize("precision,pol,tol_f,tol_g", [("fp32", FP32, 5e-5, 5e-4), ("bf16", BF16G, 2e-2, 8e-2)])
+def test_bert_large_dimensions_engine_vs_oracle(dev, precision, pol, tol_f, tol_g):
+    """J1 (BASELINE configs[3]) at BERT-large's OWN dimensions — hidden 1024, 16 heads, FFN 4096, S = 256 — two layers, B = 2:
+    forward and every parameter gradient against the oracle (fp32 tight; bf16 against the bf16 storage policy with rounded
+    gradients). The tile / K-split choices for N in {1024, 3072, 4096}, K in {1024, 4096}, the S = 256 attention forward and its
+    recompute backward, and LayerNorm at H = 1024 are exactly the code BERT-large runs; depth adds nothing new (test_c3 runs all
+    24 layers)."""
+    torch.manual_seed(0)
+    cfg = dict(hidden=1024, layers=2, heads=16, intermediate=4096, vocab=2000, max_pos=256, type_vocab=2, ln_eps=1e-12)
+    net = BertTextNet(cfg)
+    net.precision = precision
+    sd = cpu_state(net)
+    B, S = 2, 256
+    _, ids, mask, _ = synth_batch(B, S, 32, 32, cfg["vocab"], seed=5)
+    mask[1, S - 37:] = 0
+    wgt = torch.randn(B, 256, generator=torch.Generator().manual_seed(9))
+
+    def feat_fn(work):
+        _, pooled = bert_forward(work, "bert.", ids, mask, cfg, pol)
+        return pooled @ pol.qw(work["proj.weight"]).t() + work["proj.bias"]
+
+    ref = feat_fn(sd)
+    net.to(dev)
+    out = net(ids.to(dev), mask.to(dev))
+    assert rel_err(out, ref) < tol_f, f"BERT-large-dims feature ({precision}) {rel_err(out, ref)}"
+    (out * wgt.to(dev)).sum().backward()
+    names = [n for n, _ in net.named_parameters()]
+    ref_g = _oracle_grads(sd, names, lambda w: (feat_fn(w) * wgt).sum())
+    _check_grads(_grads(net), ref_g, tol_g, f"BERT-large dims {precision}", l2=True)
 
 
 def test_bert_base_full_size_backward_bf16(dev):
