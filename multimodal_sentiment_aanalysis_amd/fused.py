@@ -133,7 +133,11 @@ class FlatAdamW:
     working copy untouched and does not advance the bias-correction step count (a device int32)."""
 
     def __init__(self, state, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, ranges=None,
-                 norm_ranges=None):
+                 norm_ranges=None, clip_in_place=False):
+        """clip_in_place: also scale the optimizer's OWN gradients by the clip coefficient after the step, as
+        clip_grad_norm_ does (the AdamW kernel applies the coefficient on the fly and leaves g alone; only a caller that reads or
+        re-uses those gradients after the step — a later curriculum phase whose clip norm includes them — needs them scaled)."""
+        self.clip_in_place = bool(clip_in_place)
         self.state, self.lr, self.wd, self.betas, self.eps, self.max_norm = state, lr, weight_decay, betas, eps, max_norm
         dev = state.flat_w.device
         n = state.flat_w.numel()
@@ -182,7 +186,7 @@ class FlatAdamW:
                                         ptr(self.v[a:a + n]), ptr(w16), n, self.lr, self.betas[0], self.betas[1], self.eps,
                                         self.wd, ptr(self.steps), ptr(self.norm_out), grad_scale, stream_ptr()),
                   "mmsa_adamw_step_dev")
-        for a, n in self.extra_ranges:
+        for a, n in (self.extra_ranges + self.ranges if self.clip_in_place else self.extra_ranges):
             check(L.mmsa_grad_scale_clip(ptr(st.flat_g[a:a + n]), n, ptr(self.norm_out), stream_ptr()), "mmsa_grad_scale_clip")
         if self.ranges == [(0, st.flat_w.numel())]:
             for e, _, _ in st.ranges:
@@ -249,7 +253,10 @@ class PhaseOptimizer:
         self.opt_params = [p for m in opt_modules for p in m.parameters()]
         self.opt_ranges = param_ranges(state, self.opt_params)
         self.param_groups = [{"lr": lr}]
-        self.adamw = FlatAdamW(state, lr=lr, weight_decay=weight_decay, max_norm=max_norm, ranges=self.opt_ranges)
+        # clip_in_place: the gradients a phase leaves behind are the CLIPPED ones (torch scales .grad in place), and the next
+        # phase's norms include them (stale gradients of modules frozen later; accumulation onto them in phase 3)
+        self.adamw = FlatAdamW(state, lr=lr, weight_decay=weight_decay, max_norm=max_norm, ranges=self.opt_ranges,
+                               clip_in_place=True)
         self.norm_history = None
         self._live_key = None
 

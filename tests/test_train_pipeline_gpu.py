@@ -43,7 +43,7 @@ def _loaders():
 
 
 def _params(*mods):
-    return {f"{i}.{n}": p.detach().clone() for i, m in enumerate(mods) for n, p in m.named_parameters()}
+    return {f"{i}.{n}": p.detach().cpu().clone() for i, m in enumerate(mods) for n, p in m.named_parameters()}
 
 
 def _agree(a, b, lr, steps, what):
@@ -70,6 +70,12 @@ def test_train_py_two_stage_pipeline(dev, capsys):
         moved = sum(not torch.equal(start[k], after1[k]) for k in start)
         assert moved > 0.9 * len(start), f"stage 1 moved {moved} of {len(start)} tensors"
         assert all(torch.isfinite(v).all() for v in after1.values())
+        # stage 2 is compared from IDENTICAL encoders (the two stage-1 runs differ by Adam-step rounding, which would show up as
+        # different features, hence different classifier gradients): the second run adopts the first run's encoder
+        if "enc_state" in runs:
+            enc.load_state_dict(runs["enc_state"])
+        else:
+            runs["enc_state"] = {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}
         enc_before, clf_before = _params(enc), _params(clf)
         T.finetune_trainer(enc, clf, sup, sup, num_epochs=1, lr=1e-3, device=dev, hip_optimizer=hip)
         enc_after, clf_after = _params(enc), _params(clf)
