@@ -98,30 +98,43 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restri
 // thread walking 64 LDS values in double took ~3 us of these 6 us launches; 114 of them per step).
 #define BN_FIN_COLS 4
 #define BN_FIN_LANES 64
-template <typename V>
-__device__ __forceinline__ V bn_fin_reduce(V v, V* red /* [4][BN_FIN_COLS] */) {
+template <typename V, int COLS = BN_FIN_COLS>
+__device__ __forceinline__ V bn_fin_reduce(V v, V* red /* [4][COLS] */) {
 #pragma unroll
-  for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);  // lanes with the same column inside the wave
-  const int cc = threadIdx.x & (BN_FIN_COLS - 1), wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) < BN_FIN_COLS) red[wave * BN_FIN_COLS + cc] = v;
+  for (int o = COLS; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);  // lanes with the same column inside the wave
+  const int cc = threadIdx.x & (COLS - 1), wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < COLS) red[wave * COLS + cc] = v;
   __syncthreads();
-  return red[cc] + red[BN_FIN_COLS + cc] + red[2 * BN_FIN_COLS + cc] + red[3 * BN_FIN_COLS + cc];
+  return red[cc] + red[COLS + cc] + red[2 * COLS + cc] + red[3 * COLS + cc];
 }
+// COLS columns per workgroup, 256 / COLS partial-lanes per column. COLS = 1 is for the per-slice partials of the convolution
+// epilogues (GemmParams::colstat: up to 12544 rows of only 64-256 columns): with 4 columns per workgroup a C = 64 layer ran on 16
+// workgroups whose threads each walked 49 rows (10 us against 5.9 for the 1024-chunk partials of the streamed statistics pass)
+template <int COLS>
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int M, int C,
                                                                 float eps, float momentum, float* __restrict__ mean,
                                                                 float* __restrict__ invstd, float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var) {
-  __shared__ double rs[4 * BN_FIN_COLS], rq[4 * BN_FIN_COLS];
-  const int cc = threadIdx.x & (BN_FIN_COLS - 1), r = threadIdx.x / BN_FIN_COLS;
-  const int c = blockIdx.x * BN_FIN_COLS + cc;
+  __shared__ double rs[4 * COLS], rq[4 * COLS];
+  constexpr int LANES = 256 / COLS;
+  const int cc = threadIdx.x & (COLS - 1), r = threadIdx.x / COLS;
+  const int c = blockIdx.x * COLS + cc;
   double s = 0, q = 0;
-  if (c < C)
-    for (int b = r; b < chunks; b += BN_FIN_LANES) {
+  if (c < C) {
+    int b = r;
+    for (; b + LANES < chunks; b += 2 * LANES) {  // two rows (four loads) in flight per thread
+      const float s0 = part[((long)b * 2 + 0) * C + c], q0 = part[((long)b * 2 + 1) * C + c];
+      const float s1 = part[((long)(b + LANES) * 2 + 0) * C + c], q1 = part[((long)(b + LANES) * 2 + 1) * C + c];
+      s += s0; q += q0;
+      s += s1; q += q1;
+    }
+    for (; b < chunks; b += LANES) {
       s += part[((long)b * 2 + 0) * C + c];
       q += part[((long)b * 2 + 1) * C + c];
     }
-  s = bn_fin_reduce(s, rs);
-  q = bn_fin_reduce(q, rq);
+  }
+  s = bn_fin_reduce<double, COLS>(s, rs);
+  q = bn_fin_reduce<double, COLS>(q, rq);
   if (r != 0 || c >= C) return;
   const double mu = s / M;
   double var = q / M - mu * mu;
@@ -133,6 +146,15 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
     running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
     running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
   }
+}
+static void launch_stats_finalize(const float* part, int chunks, int M, int C, float eps, float momentum, float* mean,
+                                  float* invstd, float* running_mean, float* running_var, hipStream_t st) {
+  if ((long)chunks * BN_FIN_COLS >= 2048 && C <= 512)
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<1>, dim3(C), dim3(256), 0, st, part, chunks, M, C, eps, momentum, mean, invstd,
+                       running_mean, running_var);
+  else
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<BN_FIN_COLS>, dim3(cdiv(C, BN_FIN_COLS)), dim3(256), 0, st, part, chunks, M, C,
+                       eps, momentum, mean, invstd, running_mean, running_var);
 }
 
 // eval mode: statistics come from the running buffers
@@ -443,14 +465,15 @@ size_t bn_ws_bytes(int C) { return ((size_t)BN_CHUNKS * 2 * C + 2 * C) * sizeof(
 template <typename T>
 static int bn_forward_t(const T* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                         float* mean, float* invstd, const T* res, T* y, float* ws, int M, int C, float eps, float momentum,
-                        int act, int training, hipStream_t st, unsigned char* mask) {
+                        int act, int training, hipStream_t st, unsigned char* mask, const float* pre_part, int pre_rows) {
   const BnMap m = bn_map(C);
-  if (training) {
+  if (training && pre_part && pre_rows > 0) {  // the producer of x already summed its columns slice by slice
+    launch_stats_finalize(pre_part, pre_rows, M, C, eps, momentum, mean, invstd, running_mean, running_var, st);
+  } else if (training) {
     const int rpc = max(cdiv(M, BN_CHUNKS), m.rlanes * bn_rows_per_lane());
     const int chunks = cdiv(M, rpc);
     hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(chunks, m.cgroups), dim3(256), 0, st, x, ws, M, C, m.cthreads, rpc);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, BN_FIN_COLS)), dim3(256), 0, st, (const float*)ws, chunks, M, C, eps,
-                       momentum, mean, invstd, running_mean, running_var);
+    launch_stats_finalize((const float*)ws, chunks, M, C, eps, momentum, mean, invstd, running_mean, running_var, st);
   } else {
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)running_mean,
                        (const float*)running_var, eps, C, mean, invstd);
@@ -464,7 +487,7 @@ static int bn_forward_t(const T* x, const float* gamma, const float* beta, float
 
 int bn_forward(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                float* mean, float* invstd, const void* res, void* y, float* ws, int M, int C, float eps, float momentum,
-               int act, int training, hipStream_t st, unsigned char* relu_mask) {
+               int act, int training, hipStream_t st, unsigned char* relu_mask, const float* pre_part, int pre_rows) {
   if (C % 8 || M <= 0) return MMSA_ERR_ARG;
   if (!training && (!running_mean || !running_var)) return MMSA_ERR_ARG;
   if (relu_mask && act != MMSA_ACT_RELU) return MMSA_ERR_ARG;
@@ -476,9 +499,9 @@ int bn_forward(int dtype, const void* x, const float* gamma, const float* beta, 
   }
   if (dtype == MMSA_BF16)
     return bn_forward_t<bf16>((const bf16*)x, gamma, beta, running_mean, running_var, mean, invstd, (const bf16*)res,
-                              (bf16*)y, ws, M, C, eps, momentum, act, training, st, relu_mask);
+                              (bf16*)y, ws, M, C, eps, momentum, act, training, st, relu_mask, pre_part, pre_rows);
   return bn_forward_t<float>((const float*)x, gamma, beta, running_mean, running_var, mean, invstd, (const float*)res,
-                             (float*)y, ws, M, C, eps, momentum, act, training, st, relu_mask);
+                             (float*)y, ws, M, C, eps, momentum, act, training, st, relu_mask, pre_part, pre_rows);
 }
 
 template <typename T>

@@ -76,6 +76,14 @@ struct GemmParams {
   // batch-row kernel only (gemm_f32_tiny.hip): B is a [K][1] column of ones that is never read (N must be 1): the product
   // is the column sum of the k-major A, i.e. a bias gradient as one more problem of a grouped launch
   int b_ones;
+  // optional per-column statistics of the STORED output (the BatchNorm batch statistics of a convolution's output, taken in the
+  // conv GEMM's own epilogue instead of a separate pass over z: resnet_engine.hip): colstat[row][2][N] receives, for every 64-row
+  // slice `row` of the output, sum_m q(C[m][n]) and sum_m q(C[m][n])^2 (q = the rounding to the storage type). Only the persistent
+  // kernel's plain bf16 store epilogue without a K split produces them; *colstat_rows (host) is set to the number of slices
+  // written (cdiv(M, 64)), or 0 when this launch did not (the caller then runs its own statistics pass).
+  float* colstat;
+  long colstat_cap;       // capacity of colstat in floats
+  int* colstat_rows;
   // optional in-kernel timing record {min start, max end} in s_memrealtime ticks (100 MHz), filled by the MFMA kernels
   // and the split-K reducer when non-null (bench.py roofline: HIP event pairs add ~12 us of queue drain per launch)
   unsigned long long* stamp;

@@ -58,6 +58,8 @@ struct G2Sched {
     unsigned a_bytes, b_bytes, c_bytes;
   } grp[G2_MAX_GROUPS];
   unsigned long long* stamp;  // in-kernel timing record or null
+  unsigned colstat_bytes;
+  float* colstat;        // per-64-row-slice column sums / sums of squares of the stored bf16 output (GemmParams::colstat) or null
   int dbg;               // timing-only ablations (MMSA_G2_DBG bitmask; results are wrong): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no epilogue
 };
 
@@ -101,6 +103,16 @@ __device__ __forceinline__ bf16x8 lds_rd_tr(unsigned addr) {  // k rows kb..kb+3
   typedef __attribute__((ext_vector_type(4))) int i32x4_;
   i32x4_ r = {lo[0], lo[1], hi[0], hi[1]};
   return __builtin_bit_cast(bf16x8, r);
+}
+
+// sum of v over the 16 lanes of a DPP row (lanes 16g .. 16g+15), left in every lane of the row: xor-1 and xor-2 exchanges inside
+// the quads, then the mirror of each 8-lane half (quad 0 <-> quad 1) and of the whole row (lower 8 <-> upper 8)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
+  return v;
 }
 
 // WM = wave rows: 4 -> 256-row tile, waves 4(M) x 2(N); 2 -> 128-row tile, waves 2(M) x 4(N) (twice the tiles for
@@ -438,6 +450,37 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
             __builtin_amdgcn_raw_buffer_store_b128(d, rsrcC, vo, 0, 0);
           }
         }
+      }
+      if (s.colstat && !p.out_f32) {
+        // BatchNorm batch statistics of this tile's stored values (GemmParams::colstat): per lane the sums over its 4 row tiles,
+        // then over the 16 lanes of its lane row (= the wave's 64 rows); the lanes with r16 == 0 hold 4 consecutive columns per
+        // column tile and store them: 2 NJ store instructions = one more unit of the counted waits
+        f32x4 cs[NJ], cq[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          cq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float q = (float)(bf16)acc[i][j][r];
+              cs[j][r] += q;
+              cq[j][r] += q * q;
+            }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { cs[j][r] = row16_sum(cs[j][r]); cq[j][r] = row16_sum(cq[j][r]); }
+        }
+        __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc((void*)s.colstat, 0, s.colstat_bytes, 0x00020000);
+        const long prow = (long)(C.m0 >> 6) + wm;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int n = nb + j * 16;
+          const bool ok = r16 == 0 && n < eN;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, cs[j]), rst, ok ? (int)(((prow * 2 + 0) * eN + n) * 4) : OOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, cq[j]), rst, ok ? (int)(((prow * 2 + 1) * eN + n) * 4) : OOB, 0, 0);
+        }
+        return 2;
       }
       if constexpr (GCOLSUM) {
         if (e_colsum) {  // bias gradient of this row panel: lanes of lane-row 0 of the wn = 0 waves hold it
@@ -1053,6 +1096,18 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   s.dbg = 0;
   s.ngroups = 0;
   s.stamp = p.stamp;
+  s.colstat = nullptr;
+  s.colstat_bytes = 0;
+  if (p.colstat_rows) *p.colstat_rows = 0;
+  if (p.colstat && p.colstat_rows && s.fast && s.split_k == 1 && !p.out_f32 && p.c_gw == 0 && !p.scale_a) {
+    const long rows = cdiv(p.M, 64), need = rows * 2 * p.N;
+    // (a 128- or 256-row tile may start a slice past cdiv(M, 64): those rows are zero and their stores are dropped by the range check)
+    if (need <= p.colstat_cap && need * 4 < 0x7FFFFFF0L) {
+      s.colstat = p.colstat;
+      s.colstat_bytes = (unsigned)(need * 4);
+      *p.colstat_rows = (int)rows;
+    }
+  }
   if (const char* d = getenv("MMSA_G2_DBG")) s.dbg = atoi(d);
   s.c_bytes = s.split_k > 1 ? (unsigned)slab_bytes : (unsigned)(((long)(p.M - 1) * p.ldc + p.N) * (p.out_f32 ? 4 : 2));
   if (p.c_gw > 0) {

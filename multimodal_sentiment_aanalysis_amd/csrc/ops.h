@@ -51,7 +51,10 @@ int supcon_fwd_bwd(const float* z1, const float* z2, const long long* labels, fl
 size_t bn_ws_bytes(int C);
 int bn_forward(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                float* mean, float* invstd, const void* res, void* y, float* ws, int M, int C, float eps, float momentum,
-               int act, int training, hipStream_t st, unsigned char* relu_mask = nullptr);
+               int act, int training, hipStream_t st, unsigned char* relu_mask = nullptr, const float* pre_part = nullptr,
+               int pre_rows = 0);
+// pre_part / pre_rows (training): per-slice column sums [pre_rows][2][C] of x already taken by its producer (the convolution
+// GEMM's epilogue, GemmParams::colstat): the statistics pass over x is skipped, the finalize reads these partials.
 int bn_backward(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
                 const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
                 float* ws, int M, int C, int act, int training, hipStream_t st, const unsigned char* relu_mask = nullptr);

@@ -95,6 +95,7 @@ struct ResWs {
   void *pooled, *dfeat_t, *dpooled;
   void *g0, *g1, *g2, *g3;  // gradient ping-pong buffers (largest activation size)
   float *stem_dw, *splitk, *colws, *bnws;
+  long bnws_floats;  // capacity of the partial-sum part of bnws (conv-epilogue statistics: GemmParams::colstat_cap)
   size_t splitk_bytes;
   size_t total;
 };
@@ -156,6 +157,7 @@ static ResWs res_ws(const mmsa_resnet_cfg& c, const ResLayout& L, void* base) {
   w.splitk = (float*)b.take(w.splitk_bytes);
   w.colws = (float*)b.take(colsum_ws_bytes(maxc > c.out_dim ? maxc : c.out_dim));
   w.bnws = (float*)b.take(bn_ws_bytes(maxc));
+  w.bnws_floats = (long)(bn_ws_bytes(maxc) / sizeof(float)) - 2L * maxc;  // the partial-sum part (the tail holds the backward's sums)
   w.total = b.off;
   return w;
 }
@@ -180,12 +182,28 @@ static void set_geom(ConvGeom& g, int SH, int SW, int GH, int GW, int k, int mul
   g.fd_gw = make_fastdiv(GW); g.fd_ghw = make_fastdiv(GH * GW); g.fd_kw = make_fastdiv(k); g.fd_cper = make_fastdiv(cper);
 }
 
+// BatchNorm statistics taken by the convolution GEMM's epilogue (GemmParams::colstat): `rows` > 0 after a conv_fwd that produced
+// them into `part` (training mode, bf16 MFMA path, no K split), 0 when the BatchNorm has to run its own statistics pass.
+// MMSA_NO_CONV_STATS=1 turns the fusion off (A/B hook).
+struct ConvStats {
+  float* part;
+  long cap;
+  int rows;
+};
+static bool conv_stats_on() {
+  const char* v = getenv("MMSA_NO_CONV_STATS");  // read per call so that a test can compare both paths in one process
+  return !(v && atoi(v) != 0);
+}
 // z[B*Ho*Wo][Cout] = conv(x)
-static int conv_fwd(const ResCtx& r, const ConvDef& c, const void* x, void* z) {
+static int conv_fwd(const ResCtx& r, const ConvDef& c, const void* x, void* z, ConvStats* cs = nullptr) {
   const int B = r.c.batch, M = B * c.Hout * c.Wout, K = c.k * c.k * c.Cin;
   GemmParams p = Eng::blank();
   p.A = x; p.lda = c.Cin; p.B = r.W(c.w); p.ldb = K; p.C = z; p.ldc = c.Cout;
   p.M = M; p.N = c.Cout; p.K = K;
+  if (cs) {
+    cs->rows = 0;
+    if (r.c.training && r.c.dtype == MMSA_BF16 && conv_stats_on()) { p.colstat = cs->part; p.colstat_cap = cs->cap; p.colstat_rows = &cs->rows; }
+  }
   if (!(c.k == 1 && c.stride == 1)) {
     p.gather = 1;
     set_geom(p.g, c.Hin, c.Win, c.Hout, c.Wout, c.k, c.stride, 1, -c.pad, 1, c.Cin);
@@ -285,10 +303,12 @@ static unsigned char* bn_mask(const ConvWs& w, int act) {
   static const bool off = [] { const char* v = getenv("MMSA_NO_BN_MASK"); return v && atoi(v) != 0; }();
   return (off || act != MMSA_ACT_RELU) ? nullptr : w.mask;
 }
-static int bn_fwd(const ResCtx& r, const ConvDef& c, const ConvWs& w, const void* res, void* y, int act, float* bnws) {
+static int bn_fwd(const ResCtx& r, const ConvDef& c, const ConvWs& w, const void* res, void* y, int act, float* bnws,
+                  const ConvStats* cs = nullptr) {
   const int M = r.c.batch * c.Hout * c.Wout;
   return bn_forward(r.c.dtype, w.z, r.P(c.g), r.P(c.b), r.bnbuf + c.rm, r.bnbuf + c.rv, w.mean, w.invstd, res, y, bnws, M,
-                    c.Cout, r.c.bn_eps, r.c.bn_momentum, act, r.c.training, r.e.st, bn_mask(w, act));
+                    c.Cout, r.c.bn_eps, r.c.bn_momentum, act, r.c.training, r.e.st, bn_mask(w, act),
+                    cs && cs->rows > 0 ? cs->part : nullptr, cs ? cs->rows : 0);
 }
 // param_grads = false (a wholly frozen bottleneck): only the data gradient is produced, dgamma / dbeta are not written
 static int bn_bwd(const ResCtx& r, const ConvDef& c, const ConvWs& w, const void* dy, const void* y, void* dz, void* dres,
@@ -364,25 +384,34 @@ int mmsa_resnet_fwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
   const int M0 = B * s.Hout * s.Wout;
   RET_IF(stem_im2col(c.dtype, image, ws.col, B, 3, c.height, c.width, s.Hout, s.Wout, 7, 7, 2, 3, L.Kstem_pad, st));
   RET_IF(pad_rows(c.dtype, w32 + s.w, ws.stem_w, 64, 147, L.Kstem_pad, st));
-  RET_IF(r.e.linear_fwd(ws.col, L.Kstem_pad, ws.stem_w, nullptr, ws.stem.z, 64, M0, 64, L.Kstem_pad));
-  RET_IF(bn_fwd(r, s, ws.stem, nullptr, ws.stem.y, MMSA_ACT_RELU, ws.bnws));
+  // every convolution's GEMM also sums the columns of the z it stores (per 64-row slice, into the BatchNorm scratch), so the
+  // BatchNorm that follows starts at its finalize: one streamed pass over z less per convolution
+  ConvStats cs{ws.bnws, ws.bnws_floats, 0};
+  {
+    GemmParams p = Eng::blank();
+    p.A = ws.col; p.lda = L.Kstem_pad; p.B = ws.stem_w; p.ldb = L.Kstem_pad; p.C = ws.stem.z; p.ldc = 64;
+    p.M = M0; p.N = 64; p.K = L.Kstem_pad;
+    if (c.training && c.dtype == MMSA_BF16 && conv_stats_on()) { p.colstat = cs.part; p.colstat_cap = cs.cap; p.colstat_rows = &cs.rows; }
+    RET_IF(r.e.gemm(p));
+  }
+  RET_IF(bn_fwd(r, s, ws.stem, nullptr, ws.stem.y, MMSA_ACT_RELU, ws.bnws, &cs));
   RET_IF(maxpool_fwd(c.dtype, ws.stem.y, ws.pool, ws.pool_idx, B, s.Hout, s.Wout, 64, st));
   const void* x = ws.pool;
   for (size_t i = 0; i < L.blocks.size(); ++i) {
     const BlockDef& bd = L.blocks[i];
     BlockWs& bw = ws.blocks[i];
-    RET_IF(conv_fwd(r, bd.c1, x, bw.c1.z));
-    RET_IF(bn_fwd(r, bd.c1, bw.c1, nullptr, bw.c1.y, MMSA_ACT_RELU, ws.bnws));
-    RET_IF(conv_fwd(r, bd.c2, bw.c1.y, bw.c2.z));
-    RET_IF(bn_fwd(r, bd.c2, bw.c2, nullptr, bw.c2.y, MMSA_ACT_RELU, ws.bnws));
-    RET_IF(conv_fwd(r, bd.c3, bw.c2.y, bw.c3.z));
     const void* idn = x;
-    if (bd.has_ds) {
-      RET_IF(conv_fwd(r, bd.ds, x, bw.ds.z));
-      RET_IF(bn_fwd(r, bd.ds, bw.ds, nullptr, bw.ds.y, MMSA_ACT_NONE, ws.bnws));
+    if (bd.has_ds) {  // the projection shortcut first: its BatchNorm and conv3's share the statistics scratch
+      RET_IF(conv_fwd(r, bd.ds, x, bw.ds.z, &cs));
+      RET_IF(bn_fwd(r, bd.ds, bw.ds, nullptr, bw.ds.y, MMSA_ACT_NONE, ws.bnws, &cs));
       idn = bw.ds.y;
     }
-    RET_IF(bn_fwd(r, bd.c3, bw.c3, idn, bw.c3.y, MMSA_ACT_RELU, ws.bnws));
+    RET_IF(conv_fwd(r, bd.c1, x, bw.c1.z, &cs));
+    RET_IF(bn_fwd(r, bd.c1, bw.c1, nullptr, bw.c1.y, MMSA_ACT_RELU, ws.bnws, &cs));
+    RET_IF(conv_fwd(r, bd.c2, bw.c1.y, bw.c2.z, &cs));
+    RET_IF(bn_fwd(r, bd.c2, bw.c2, nullptr, bw.c2.y, MMSA_ACT_RELU, ws.bnws, &cs));
+    RET_IF(conv_fwd(r, bd.c3, bw.c2.y, bw.c3.z, &cs));
+    RET_IF(bn_fwd(r, bd.c3, bw.c3, idn, bw.c3.y, MMSA_ACT_RELU, ws.bnws, &cs));
     x = bw.c3.y;
   }
   RET_IF(avgpool_fwd(c.dtype, x, ws.pooled, B, L.Hf * L.Wf, L.feat_c, st));
