@@ -1,6 +1,7 @@
 // extern "C" surface of libmmsa_hip.so (declared in include/mmsa.h). Thin: validates, converts the plain C
 // descriptors to the internal ones, and calls the launchers.
 #include "../../include/mmsa.h"
+#include <string.h>
 #include "ops.h"
 
 int gemm_prof_begin(int max_records);
@@ -10,6 +11,7 @@ int gemm_prof_end(double* total_ms, double* total_flop, long* launches);
 
 static GemmParams to_params(const mmsa_gemm_desc* d) {
   GemmParams p;
+  memset(&p, 0, sizeof(p));  // every field the descriptor does not carry (epilogue extras, column statistics, stamps) is off
   p.A = d->A; p.B = d->B; p.C = d->C;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;

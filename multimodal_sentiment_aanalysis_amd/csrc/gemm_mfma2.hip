@@ -128,14 +128,23 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WN = 8 / WM, BM = WM * 64, BN = NJ * 16 * WN;
+  // NJ = 8 (WM = 4): the 256 x 256 tile. Half the L2->LDS bytes and 3/4 of the LDS fragment bytes per FLOP of the 256 x 128
+  // tile; a stage is A 256x64 + B 256x64 = 64 KiB, so the ring has TWO stages (128 KiB) and the refill of a stage is issued in
+  // one go right after the barrier that frees it (see the NJ == 8 main loop below).
+  constexpr bool BIG = NJ == 8;
+  static_assert(!BIG || (WM == 4 && GATHER == 0 && !FP8), "the 256 x 256 tile: plain NT / NN / TN problems only");
+  constexpr int NSTG = BIG ? 2 : 3;
+  constexpr int B_BYTES = BIG ? 32768 : G2_B_BYTES;
+  constexpr int STAGE = G2_A_BYTES + B_BYTES;
   constexpr int NPA = BM / 64;  // A LDS-DMA pieces per wave per step (a piece = 1 KiB = 8 rows)
-  constexpr int NLB = (BN <= 64 && !B_KM) ? 1 : 2;  // B LDS-DMA pieces per wave per step
+  constexpr int NLB = BIG ? 4 : ((BN <= 64 && !B_KM) ? 1 : 2);  // B LDS-DMA pieces per wave per step
   constexpr int NL = NPA + NLB;                      // LDS-DMA instructions per wave per step
   // store instructions per wave per plain epilogue, in units of 2 NJ: bf16 output = 1 unit (16 B per lane, row tiles
   // paired), fp32 output / split-K slabs = 2 units. The counted waits need the exact number.
-  constexpr int NSU = 2 * NJ;
+  constexpr int NSU = BIG ? NJ : 2 * NJ;  // (the 256 x 256 tile counts its stores in units of NJ = 8 instructions)
   constexpr int OOB = (int)0x80000000;
   const int tid = threadIdx.x, lane = tid & 63;
+  int lane_ = lane;  // the 256 x 256 loop makes this copy opaque once per K step: what is derived from it is recomputed, not kept
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = WM == 4 ? wave >> 1 : wave >> 2, wn = WM == 4 ? wave & 1 : wave & 3;
 
@@ -219,9 +228,13 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     if constexpr (!A_KM) return (int)(((long)rcA_of(i) * llda + kc8) * 2);
     else return (int)(((long)krow_km(wave * NPA + i) * llda + rcA_of(i)) * 2);
   };
-  auto krowB_of = [&](int i) __attribute__((always_inline)) -> int { return 4 * (wave * NLB + i) + (lane >> 4); };
+  auto krowB_of = [&](int i) __attribute__((always_inline)) -> int {
+    if constexpr (BIG) return krow_km(wave * NLB + i);  // two [64][128] halves, piece = 4 k-rows of one half (as the A image)
+    else return 4 * (wave * NLB + i) + (lane >> 4);
+  };
   auto rcB_of = [&](int i) __attribute__((always_inline)) -> int {
     if constexpr (!B_KM) return (wave * NLB + i) * 8 + (lane >> 3);
+    else if constexpr (BIG) return ((wave * NLB + i) >> 4) * 128 + col_km(krowB_of(i));
     else return col_km(krowB_of(i));
   };
   auto relB_of = [&](int i) __attribute__((always_inline)) -> int {
@@ -241,6 +254,28 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   int a_base[NPA];                         // GATHER 1, div == 1: element offset of (img, yb, xb) in the source (may be out of range)
   int b_ky[NLB], b_kx[NLB], b_coff[NLB];  // GATHER 2: tap and channel offset of the lane's B column chunks
   int l_grp = -1;
+  // The 256 x 256 tile keeps ONE per-lane source offset per operand (two for a k-major operand: the column swizzle of a piece
+  // depends on bit 3 of its k row) and adds the piece's own offset as a scalar (soffset): 8 per-lane offsets were 8 more
+  // loop-carried VGPRs than the allocator had (spilled, and each reload drains the DMA ring). No range masks: a row / column
+  // past the problem only feeds outputs the epilogue does not store, and the descriptors bound the reads.
+  int vA[2] = {0, 0}, vB[2] = {0, 0};
+  auto big_lane_offset = [&](bool km, long ld, int bit) __attribute__((always_inline)) -> int {
+    const int ln = lane_;
+    if (!km) return ((ln >> 3) * (int)ld + (((ln & 7) ^ (ln >> 3)) * 8)) * 2;
+    const int pc = ln & 15, swz = (ln >> 4) | (bit << 2);
+    const int colkm = ((((pc >> 1) ^ swz) << 1) | (pc & 1)) * 8;
+    return ((ln >> 4) * (int)ld + colkm) * 2;
+  };
+  auto big_piece_soff = [&](bool km, long ld, int pi) __attribute__((always_inline)) -> int {  // scalar: pi is wave-uniform
+    if (!km) return (int)((long)pi * 8 * ld * 2);
+    return (int)(((long)(4 * (pi & 15)) * ld + (pi >> 4) * 128) * 2);
+  };
+  auto big_offsets = [&]() __attribute__((always_inline)) {  // (per DMA burst: the offsets are not kept across the K loop)
+    vA[0] = big_lane_offset(A_KM, llda, 0);
+    if constexpr (A_KM) vA[1] = big_lane_offset(true, llda, 1);
+    vB[0] = big_lane_offset(B_KM, lldb, 0);
+    if constexpr (B_KM) vB[1] = big_lane_offset(true, lldb, 1);
+  };
   auto loader_setup = [&]() __attribute__((always_inline)) {
     if constexpr (GROUPS) {
       if (s.ngroups > 0 && L.grp != l_grp) {  // the loader enters another problem of the group
@@ -250,6 +285,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
         rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)s.grp[l_grp].B, 0, s.grp[l_grp].b_bytes, 0x00020000);
       }
     }
+    if constexpr (BIG) return;  // big_offsets() at every DMA burst
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       if constexpr (GATHER == 1) {
@@ -328,11 +364,23 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   auto dma_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_c)::value;
     if constexpr (pc < NPA) {
-      unsigned char* sa = smem + stage * G2_STAGE + wave * (NPA * 1024) + pc * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)sa, 16, voffA[pc], d_soffA, 0, 0);
+      unsigned char* sa = smem + stage * STAGE + wave * (NPA * 1024) + pc * 1024;
+      if constexpr (BIG) {
+        const int pi = wave * NPA + pc;
+        const int vo = A_KM ? ((((pi & 15) >> 1) & 1) ? vA[1] : vA[0]) : vA[0];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)sa, 16, vo, d_soffA + big_piece_soff(A_KM, llda, pi), 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)sa, 16, voffA[pc], d_soffA, 0, 0);
+      }
     } else if constexpr (pc < NL) {
-      unsigned char* sb = smem + stage * G2_STAGE + G2_A_BYTES + wave * (NLB * 1024) + (pc - NPA) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)sb, 16, voffB[pc - NPA], d_soffB, 0, 0);
+      unsigned char* sb = smem + stage * STAGE + G2_A_BYTES + wave * (NLB * 1024) + (pc - NPA) * 1024;
+      if constexpr (BIG) {
+        const int pi = wave * NLB + (pc - NPA);
+        const int vo = B_KM ? ((((pi & 15) >> 1) & 1) ? vB[1] : vB[0]) : vB[0];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)sb, 16, vo, d_soffB + big_piece_soff(B_KM, lldb, pi), 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)sb, 16, voffB[pc - NPA], d_soffB, 0, 0);
+      }
     }
   };
   auto dma_advance = [&]() __attribute__((always_inline)) {
@@ -347,12 +395,15 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   };
   auto issue = [&](int stage) __attribute__((always_inline)) {
     dma_begin();
+    if constexpr (BIG) big_offsets();
     dma_piece(stage, std::integral_constant<int, 0>{});
     dma_piece(stage, std::integral_constant<int, 1>{});
     dma_piece(stage, std::integral_constant<int, 2>{});
     dma_piece(stage, std::integral_constant<int, 3>{});
     dma_piece(stage, std::integral_constant<int, 4>{});
     dma_piece(stage, std::integral_constant<int, 5>{});
+    dma_piece(stage, std::integral_constant<int, 6>{});
+    dma_piece(stage, std::integral_constant<int, 7>{});
     dma_advance();
   };
 
@@ -387,6 +438,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   float fp8_alpha = 1.f;
   if constexpr (FP8) fp8_alpha = p.scale_a[0] * p.scale_b[0];
   auto epilogue = [&]() __attribute__((always_inline)) -> int {  // returns the store units it issued (0: it drained the queue)
+    const int r16 = lane_ & 15, g4 = lane_ >> 4;  // (= the outer ones; re-derived so that they are not live across the K loop)
     const int mb = C.m0 + wm * 64 + r16, nb = C.n0 + wn * (NJ * 16) + 4 * g4;
     if constexpr (FP8) {
 #pragma unroll
@@ -406,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, acc[i][j]), rsrcC, vo, 0, 0);
         }
       }
-      return 2;
+      return BIG ? 4 : 2;
     }
     if (s.fast) {
       if (p.out_f32) {
@@ -451,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
           }
         }
       }
-      if (s.colstat && !p.out_f32) {
+      if (!BIG && s.colstat && !p.out_f32) {
         // BatchNorm batch statistics of this tile's stored values (GemmParams::colstat): per lane the sums over its 4 row tiles,
         // then over the 16 lanes of its lane row (= the wave's 64 rows); the lanes with r16 == 0 hold 4 consecutive columns per
         // column tile and store them: 2 NJ store instructions = one more unit of the counted waits
@@ -495,32 +547,42 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
           return 0;
         }
       }
-      return p.out_f32 ? 2 : 1;
+      return (p.out_f32 ? 2 : 1) * (BIG ? 2 : 1);
     }
     // general epilogue (reads bias / side operands), then a full drain so the counted waits of the following steps
     // see an empty queue. All side-operand loads of the tile are issued up front, branch-free through buffer
     // descriptors (out-of-range lanes read 0), and awaited once: as a per-sub-tile load -> use -> store chain it cost
     // 16 dependent memory round trips per tile (FFN GEMMs ran at 420-470 TF/s against 750 for the plain store).
     if (!(p.out_f32 && p.accumulate)) {
+      // The 256 x 256 tile (NJ = 8) runs this epilogue in two passes of four column tiles each: with all eight at once the side
+      // operands (64 VGPRs) and biases (32) on top of 128 accumulators and the loop's prefetched fragments spilled ~500 VGPRs.
+      constexpr int JW = BIG ? 4 : NJ;
+      int units = 0;
+      auto part = [&](auto j0_c) __attribute__((always_inline)) {
+      constexpr int J0 = decltype(j0_c)::value;
       const long cext = (long)(p.M - 1);
-      f32x4 bias4[NJ];
-      i32x2 side[4][NJ];  // gelu' operand, or the residual when there is no gelu' operand (both: a second batch)
-      const bool has_mul = p.mul != nullptr, has_add = p.add != nullptr;
+      f32x4 bias4[JW];
+      // gelu' operand, or the residual when there is no gelu' operand (both: a second batch). The 256 x 256 tile takes no side
+      // operands (the planner keeps such problems on the smaller tiles): 128 accumulators leave no room for them
+      i32x2 side[BIG ? 1 : 4][BIG ? 1 : JW];
+      const bool has_mul = !BIG && p.mul != nullptr, has_add = !BIG && p.add != nullptr;
       auto load_side = [&](const void* ptr, long ld) __attribute__((always_inline)) {
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, (int)((cext * ld + p.N) * 2), 0x00020000);
+        if constexpr (!BIG) {
+          __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, (int)((cext * ld + p.N) * 2), 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const int m = mb + i * 16, n = nb + j * 16;
-            side[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (m < p.M && n < p.N) ? (int)(((long)m * ld + n) * 2) : OOB, 0, 0);
-          }
+            for (int j = 0; j < JW; ++j) {
+              const int m = mb + i * 16, n = nb + (J0 + j) * 16;
+              side[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (m < p.M && n < p.N) ? (int)(((long)m * ld + n) * 2) : OOB, 0, 0);
+            }
+        }
       };
       {
         __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.N * 4 : 0, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int n = nb + j * 16;
+        for (int j = 0; j < JW; ++j) {
+          const int n = nb + (J0 + j) * 16;
           bias4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, n < p.N ? n * 4 : OOB, 0, 0));
         }
       }
@@ -550,9 +612,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
 #pragma unroll
       for (int i = 0; i < 4; i += 2) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int jj = 0; jj < JW; ++jj) {
+          const int j = J0 + jj;
 #pragma unroll
-          for (int h = 0; h < 2; ++h) acc[i + h][j] += bias4[j];
+          for (int h = 0; h < 2; ++h) acc[i + h][j] += bias4[jj];
           if (p.C2 && p.c2_gelu_grad) {  // side output = gelu'(pre-activation), from the same exp / erf as the activation
             f32x4 d0, d1;
 #pragma unroll
@@ -574,7 +637,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             if (has_mul) {
-              const f32x4 x = unpack(side[i + h][j]);
+              const f32x4 x = unpack(side[BIG ? 0 : i + h][BIG ? 0 : jj]);
               if (p.mul_is_factor) acc[i + h][j] *= x;
               else {
 #pragma unroll
@@ -595,10 +658,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
 #pragma unroll
       for (int i = 0; i < 4; i += 2) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int jj = 0; jj < JW; ++jj) {
+          const int j = J0 + jj;
           if (has_add) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) acc[i + h][j] += unpack(side[i + h][j]);
+            for (int h = 0; h < 2; ++h) acc[i + h][j] += unpack(side[BIG ? 0 : i + h][BIG ? 0 : jj]);
           }
           if (p.out_f32) {
 #pragma unroll
@@ -612,13 +676,17 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
           }
         }
       }
-      // outstanding now: the C stores (bf16 pairs: 1 unit of 2 NJ; fp32: 2 units) and, unless a second load batch was
-      // awaited after them, the side-output stores (1 unit)
-      {
-        const int units = (p.out_f32 ? 2 : 1) + ((p.C2 && !(has_mul && has_add)) ? 1 : 0);
-        return units > 2 ? 2 : units;  // the wait table covers 0..2 units; under-reporting only makes a wait stricter
+      // outstanding now: the C stores (bf16 pairs: 2 JW instructions; fp32: 4 JW) and, unless a second load batch was
+      // awaited after them, the side-output stores (2 JW). In units of NSU (2 NJ; the 256 x 256 tile counts in units of NJ = 2 JW):
+      units = (p.out_f32 ? 2 : 1) + ((p.C2 && !(has_mul && has_add)) ? 1 : 0);
+      };
+      part(std::integral_constant<int, 0>{});
+      if constexpr (BIG) {
+        __builtin_amdgcn_sched_barrier(0);
+        part(std::integral_constant<int, 4>{});  // (its wait_vm<0> also retires the first pass's stores)
       }
-    } else {  // fp32 accumulate into C without a split (rare): per-element read-modify-write
+      return units > 2 ? 2 : units;  // the wait table covers these; under-reporting only makes a wait stricter
+    } else if constexpr (!BIG) {  // fp32 accumulate into C without a split (rare): per-element read-modify-write
       f32x4 bias4[NJ];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -672,14 +740,14 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int col = wn * (NJ * 16) + j * 16 + 4 * pp;
-        offB[j] = lds0 + G2_A_BYTES + km_off(8 * g4 + q, col >> 3) + ((pp & 1) << 3);
+        offB[j] = lds0 + G2_A_BYTES + (col >> 7) * 16384 + km_off(8 * g4 + q, (col & 127) >> 3) + ((pp & 1) << 3);
       }
     }
   }
   constexpr int RD_HALF = (A_KM ? 8 : 4) + (B_KM ? 2 * NJ : NJ);  // LDS instructions of one read_half
   auto read_half = [&](auto kk_c, int stage, bf16x8(&fa)[4], bf16x8(&fb)[NJ]) __attribute__((always_inline)) {
     constexpr int kk = decltype(kk_c)::value;
-    const unsigned so = (unsigned)(stage * G2_STAGE);
+    const unsigned so = (unsigned)(stage * STAGE);
     if constexpr (!A_KM) {
       const unsigned a = offA[kk] + so;
       fa[0] = lds_rd128<0>(a); fa[1] = lds_rd128<2048>(a); fa[2] = lds_rd128<4096>(a); fa[3] = lds_rd128<6144>(a);
@@ -776,6 +844,246 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     if constexpr (PART == 1) dma_advance();
   };
 
+  if constexpr (BIG) {
+    // ---- 256 x 256 tile. LDS = FIVE slots of 32 KiB (all 160 KiB): the A tile (256 x 64) and the B tile (256 x 64) of a K step
+    // are separate slots, and the DMA stream A(0) B(0) A(1) B(1) A(2) B(2) ... runs 2.5 steps ahead of the MFMAs: while step u is
+    // computed (2 slots), step u+1 and the A tile of step u+2 are landed or in flight (3 slots = 96 KiB, as much as the 3-stage
+    // ring of the smaller tiles keeps in flight, for twice the FLOPs per byte). A two-stage ring of 64 KiB stages (the first
+    // version) could only refill after a whole stage was free: every step waited ~2 us for its own refill (no faster than 256x128).
+    // One K step = four sub-phases of 16 MFMAs, (kk, jh) = (k half, column half):
+    //   (0,0): A(kk0) x B(kk0, j 0-3)      while the reads of B(kk0, j 4-7) are in flight
+    //   (0,1): A(kk0) x B(kk0, j 4-7)      while A(kk1) and B(kk1, j 0-3) are read
+    //   (1,0): A(kk1) x B(kk1, j 0-3)      while B(kk1, j 4-7) is read   -> every read of this step's two slots has been issued
+    //   lgkmcnt(0) + counted vmcnt (B(u+1) has landed; A(u+2) and an epilogue's stores may stay in flight) + s_barrier
+    //   (1,1): A(kk1) x B(kk1, j 4-7)      while A'(kk0), B'(kk0, j 0-3) of step u+1 are read and the two freed slots are
+    //          refilled: B(u+2), then A(u+3) (4 + 4 LDS-DMA instructions per wave, one per two MFMAs); then the epilogue if the
+    //          item ends here.
+    constexpr int SLOT = 32768;
+    constexpr int RD_A = A_KM ? 8 : 4, RD_B = B_KM ? 8 : 4;  // LDS instructions of one A read / one 4-tile B read
+    // Fragment addresses are RE-DERIVED from the lane id (a handful of VALU per K step) instead of living in VGPRs across the
+    // loop: with 128 accumulators + 64 fragment registers the allocator spilled exactly these loop-invariant addresses, and every
+    // scratch reload is followed by s_waitcnt vmcnt(0) — it drains the LDS-DMA ring (CDNA4 guide, 4-wave attention pitfalls:
+    // "recompute per block"). `lane_` is made opaque once per K step so that the recomputation is not hoisted out of the loop.
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned kmA = 0, kmQ = 0, kmB = 0, kmS = 0;  // k-major fragment address parts
+    auto km_parts = [&]() __attribute__((always_inline)) {
+      const unsigned r = lane_ & 15, g = lane_ >> 4, q = r >> 2, pp = r & 3;
+      const unsigned row = (8 * g + q) * 256 + ((pp >> 1) << 4) + ((pp & 1) << 3);
+      if constexpr (A_KM) {
+        kmA = lds0 + (wm >> 1) * 16384 + row + ((((unsigned)wm & 1) ^ (g & 1)) << 7);
+        kmQ = q << 5;
+      }
+      if constexpr (B_KM) {
+        kmB = lds0 + wn * 16384 + row;
+        kmS = (q | ((g & 1) << 2)) << 5;
+      }
+    };
+    km_parts();
+    auto readA = [&](auto kk_c, int slot, bf16x8(&fa)[4]) __attribute__((always_inline)) {
+      constexpr int kk = decltype(kk_c)::value;
+      const unsigned so = (unsigned)(slot * SLOT);
+      if constexpr (!A_KM) {
+        const unsigned a = lds0 + so + kc_off(wm * 64 + (lane_ & 15), kk * 4 + (lane_ >> 4));
+        fa[0] = lds_rd128<0>(a); fa[1] = lds_rd128<2048>(a); fa[2] = lds_rd128<4096>(a); fa[3] = lds_rd128<6144>(a);
+      } else {
+        // k-major image: the address of row tile i is constA + ((i ^ q) << 5) (q = the lane's k row inside its group of four:
+        // the 32-byte XOR swizzle of km_off acts on exactly these bits), so two values stand for the four addresses
+        const unsigned a = kmA + so;
+        fa[0] = lds_rd_tr<kk * 8192>(a + ((0u << 5) ^ kmQ)); fa[1] = lds_rd_tr<kk * 8192>(a + ((1u << 5) ^ kmQ));
+        fa[2] = lds_rd_tr<kk * 8192>(a + ((2u << 5) ^ kmQ)); fa[3] = lds_rd_tr<kk * 8192>(a + ((3u << 5) ^ kmQ));
+      }
+    };
+    auto readB = [&](auto kk_c, auto jh_c, int slot, bf16x8(&fb)[4]) __attribute__((always_inline)) {
+      constexpr int kk = decltype(kk_c)::value, jh = decltype(jh_c)::value;
+      const unsigned so = (unsigned)(slot * SLOT);
+      if constexpr (!B_KM) {
+        const unsigned b = lds0 + so + kc_off(wn * (NJ * 16) + (lane_ & 15), kk * 4 + (lane_ >> 4));
+        fb[0] = lds_rd128<(jh * 4 + 0) * 2048>(b); fb[1] = lds_rd128<(jh * 4 + 1) * 2048>(b);
+        fb[2] = lds_rd128<(jh * 4 + 2) * 2048>(b); fb[3] = lds_rd128<(jh * 4 + 3) * 2048>(b);
+      } else {
+        const unsigned b = kmB + so;  // column tile j sits at constB + ((j ^ (q | (g4 & 1) << 2)) << 5)
+        fb[0] = lds_rd_tr<kk * 8192>(b + (((unsigned)(jh * 4 + 0) << 5) ^ kmS)); fb[1] = lds_rd_tr<kk * 8192>(b + (((unsigned)(jh * 4 + 1) << 5) ^ kmS));
+        fb[2] = lds_rd_tr<kk * 8192>(b + (((unsigned)(jh * 4 + 2) << 5) ^ kmS)); fb[3] = lds_rd_tr<kk * 8192>(b + (((unsigned)(jh * 4 + 3) << 5) ^ kmS));
+      }
+    };
+    // one LDS-DMA instruction (1 KiB) of the loader cursor's A / B tile into `slot`
+    auto dmaA = [&](int slot, auto pc_c) __attribute__((always_inline)) {
+      constexpr int pc = decltype(pc_c)::value;
+      unsigned char* sa = smem + slot * SLOT + wave * 4096 + pc * 1024;
+      const int pi = wave * 4 + pc;
+      const int vo = A_KM ? ((((pi & 15) >> 1) & 1) ? vA[1] : vA[0]) : vA[0];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)sa, 16, vo, d_soffA + big_piece_soff(A_KM, llda, pi), 0, 0);
+    };
+    auto dmaB = [&](int slot, auto pc_c) __attribute__((always_inline)) {
+      constexpr int pc = decltype(pc_c)::value;
+      unsigned char* sb = smem + slot * SLOT + wave * 4096 + pc * 1024;
+      const int pi = wave * 4 + pc;
+      const int vo = B_KM ? ((((pi & 15) >> 1) & 1) ? vB[1] : vB[0]) : vB[0];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)sb, 16, vo, d_soffB + big_piece_soff(B_KM, lldb, pi), 0, 0);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
+    int dslot = 0;  // slot of the next unit of the DMA stream
+    auto next_slot = [&](int sl) __attribute__((always_inline)) -> int { return sl == 4 ? 0 : sl + 1; };
+    auto unitA = [&]() __attribute__((always_inline)) {  // the cursor's A tile (the cursor has just entered this K step)
+      dma_begin();
+      big_offsets();
+      dmaA(dslot, K0{}); dmaA(dslot, K1{}); dmaA(dslot, K2{}); dmaA(dslot, K3{});
+      dslot = next_slot(dslot);
+    };
+    auto unitB = [&]() __attribute__((always_inline)) {  // the cursor's B tile, then the cursor moves to the next K step
+      dmaB(dslot, K0{}); dmaB(dslot, K1{}); dmaB(dslot, K2{}); dmaB(dslot, K3{});
+      dslot = next_slot(dslot);
+      dma_advance();
+    };
+    auto mma16 = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[4], auto jh_c) __attribute__((always_inline)) {
+      constexpr int jh = decltype(jh_c)::value;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][jh * 4 + j] = mma1(fb[j], fa[i], acc[i][jh * 4 + j]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    // eight MFMAs of sub-phase (1,1) (row tiles I0, I0 + 1) with the four LDS-DMA instructions of one unit between them
+    auto mma8_dma = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[4], auto i0_c, auto isB_c, int slot) __attribute__((always_inline)) {
+      constexpr int I0 = decltype(i0_c)::value;
+      constexpr bool ISB = decltype(isB_c)::value != 0;
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      auto one = [&](auto idx_c) __attribute__((always_inline)) {
+        constexpr int idx = decltype(idx_c)::value;
+        constexpr int i = I0 + idx / 4, j = idx % 4;
+        acc[i][4 + j] = mma1(fb[j], fa[i], acc[i][4 + j]);
+        if constexpr (idx % 2 == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (ISB) dmaB(slot, std::integral_constant<int, idx / 2>{});
+          else dmaA(slot, std::integral_constant<int, idx / 2>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+      one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+      one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+      one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma8 = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[4], auto i0_c) __attribute__((always_inline)) {
+      constexpr int I0 = decltype(i0_c)::value;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = I0; i < I0 + 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][4 + j] = mma1(fb[j], fa[i], acc[i][4 + j]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    // prologue: A(0) B(0) A(1) B(1) A(2)
+    unitA(); unitB();
+    if (total > 1) { unitA(); unitB(); }
+    if (total > 2) unitA();
+    if (total > 2) wait_vm<12>();
+    else if (total > 1) wait_vm<8>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    bf16x8 a0[4], a1[4], b0[4], b1[4];
+    int cA = 0, cB = 1;  // slots of the step being computed
+    readA(K0{}, cA, a0);
+    readB(K0{}, K0{}, cB, b0);
+    int eu1 = 0;
+    for (int u = 0; u < total; ++u) {
+      asm volatile("" : "+v"(lane_));
+      km_parts();
+      // (0,0)
+      readB(K0{}, K1{}, cB, b1);
+      wait_lgkm<RD_B>();
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(a0, b0, K0{});
+      __builtin_amdgcn_sched_barrier(0);
+      // (0,1)
+      readA(K1{}, cA, a1);
+      readB(K1{}, K0{}, cB, b0);
+      wait_lgkm<(RD_A + RD_B < 15 ? RD_A + RD_B : 14)>();  // (lgkmcnt is 4 bits: a stricter wait for the TN variant)
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(a0, b1, K1{});
+      __builtin_amdgcn_sched_barrier(0);
+      // (1,0)
+      readB(K1{}, K1{}, cB, b1);
+      wait_lgkm<RD_B>();
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(a1, b0, K0{});
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm<0>();  // every read of this step's slots has completed: they may be refilled
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + 1 < total) {
+        // B(u+1) was issued one step ago. Newer operations: the 4 pieces of A(u+2) and the stores of the epilogue that followed
+        switch (eu1 * 2 + (u + 2 < total ? 1 : 0)) {
+          case 0: wait_vm<0>(); break;
+          case 1: wait_vm<4>(); break;
+          case 2: wait_vm<NSU>(); break;
+          case 3: wait_vm<NSU + 4>(); break;
+          case 4: wait_vm<2 * NSU>(); break;
+          case 5: wait_vm<2 * NSU + 4>(); break;
+          case 6: wait_vm<3 * NSU>(); break;
+          case 7: wait_vm<3 * NSU + 4>(); break;
+          case 8: wait_vm<4 * NSU>(); break;
+          default: wait_vm<4 * NSU + 4>(); break;
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+      const int nA = cA >= 3 ? cA - 3 : cA + 2, nB = cB >= 3 ? cB - 3 : cB + 2;
+      // On the last K step of an item the read-ahead of step u+1's first fragments follows the epilogue (32 VGPRs the
+      // epilogue can use: with them live the loop's address registers were spilled, and every scratch reload waits vmcnt(0))
+      const bool item_ends = c_kt + 1 == C.nk;
+      if (u + 1 < total && !item_ends) {
+        readA(K0{}, nA, a0);
+        readB(K0{}, K0{}, nB, b0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // (1,1), with the refill of the two freed slots: B(u+2) then A(u+3)
+      if (u + 2 < total) {
+        big_offsets();  // (re-derived here too: the per-lane source offsets are not carried across the K loop)
+        mma8_dma(a1, b1, K0{}, K1{}, dslot);
+        dslot = next_slot(dslot);
+        dma_advance();
+        if (u + 3 < total) {
+          dma_begin();
+          big_offsets();
+          mma8_dma(a1, b1, K2{}, K0{}, dslot);
+          dslot = next_slot(dslot);
+        } else {
+          mma8(a1, b1, K2{});
+        }
+      } else {
+        mma16(a1, b1, K1{});
+      }
+      int e = 0;
+      if (++c_kt == C.nk) {
+        e = epilogue();
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 1 < total) {
+          readA(K0{}, nA, a0);
+          readB(K0{}, K0{}, nB, b0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        c_kt = 0;
+        c_item += G;
+        if (c_item < s.items) {
+          C = decode(c_item);
+          compute_setup();
+        }
+      }
+      eu1 = e;
+      cA = nA;
+      cB = nB;
+    }
+  } else {
   // prologue: up to three steps of DMA in flight, then wait for step 0 and read its first-half fragments
   issue(0);
   if (total > 1) issue(1);
@@ -840,6 +1148,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     }
     eu1 = e;
     st = nst;
+  }
   }
   stamp_end(s.stamp);
 #endif
@@ -946,13 +1255,21 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
   const int nsteps = p.K / G2_BK;
   G2Plan best{4, 4, 1};
   double best_cost = 1e300;
-  static const int cfgs[5][2] = {{4, 4}, {4, 3}, {4, 2}, {2, 2}, {2, 1}};
+  static const int cfgs[6][2] = {{4, 4}, {4, 3}, {4, 2}, {2, 2}, {2, 1}, {4, 8}};
+  // The 256 x 256 tile is opt-in (MMSA_G2_BIG=1, or forced per launch with MMSA_G2_NJ=4:8): measured on MI355X it ties the
+  // 256 x 128 tile on large NT / NN problems (both ~45 % of the MFMA-only time of the same loop) and loses on everything with
+  // fewer than ~256 tiles; see DESIGN.md section 3 for the ablations.
+  static const bool no_big = [] { const char* v = getenv("MMSA_G2_BIG"); return !(v && atoi(v) != 0); }();
   // epilogue class: 0 plain store, 1 bias / activation / side output (registers only), 2 reads gelu' / residual operands
   const int epi = g2_epi_class(p);
   const G2Model& mdl = g2_model();
-  for (int ci = 0; ci < 5; ++ci) {
+  for (int ci = 0; ci < 6; ++ci) {
     const G2Plan shape{cfgs[ci][0], cfgs[ci][1], 1};
     if (force_wm && (shape.wm != force_wm || shape.nj != force_nj)) continue;
+    // the 256 x 256 tile: plain problems only (no implicit-GEMM gather, no fp8 operands, no mapped output rows)
+    if (shape.nj == 8 && (p.gather || p.scale_a || p.c_gw > 0 || p.colstat || p.mul || p.add || p.a_kmajor ||
+                          (p.out_f32 && p.accumulate) || (no_big && !force_wm)))
+      continue;
     const int bm = g2_bm(shape), bn = g2_bn(shape);
     const int ntm = cdiv(p.M, bm), ntn = cdiv(p.N, bn);
     const long tiles = (long)ntm * ntn;
@@ -978,7 +1295,7 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
     // the register-only epilogue costs ~1 us per item, the one with side operands one memory round trip more; on the
     // 256x128 tile both run out of registers (accumulators + side operands + the loop's prefetched fragments: the
     // compiler spills ~60 VGPRs there), measured +3 / +8 us per item (tools/microbench/bench_small.py, bench_epi2.py)
-    static const double epi_cost[3][5] = {{0, 0, 0, 0, 0}, {3.0, 1.0, 0.9, 0.65, 0.5}, {8.0, 2.0, 1.2, 1.0, 0.8}};
+    static const double epi_cost[3][6] = {{0, 0, 0, 0, 0, 0}, {3.0, 1.0, 0.9, 0.65, 0.5, 4.0}, {8.0, 2.0, 1.2, 1.0, 0.8, 10.0}};
     static const bool no_epi = [] { const char* v = getenv("MMSA_G2_NOEPI"); return v && atoi(v) != 0; }();  // A/B hook
     const double waste = (double)ntn * bn / p.N * ((double)ntm * bm / p.M);  // padding: only as a tie breaker
     for (int c = 0; c < nc; ++c) {
@@ -997,13 +1314,14 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
 
 // plans are pure functions of the shape: memoize (one caller thread per process — include/mmsa.h)
 static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
-  struct Key { int M, N, K, epi; size_t ws; G2Plan plan; };
+  struct Key { int M, N, K, epi, big_ok; size_t ws; G2Plan plan; };
   static std::vector<Key> cache;
   const int epi = g2_epi_class(p);
+  const int big_ok = !(p.gather || p.scale_a || p.c_gw > 0 || p.colstat || p.mul || p.add || p.a_kmajor);  // which tile shapes exist
   for (const Key& k : cache)
-    if (k.M == p.M && k.N == p.N && k.K == p.K && k.epi == epi && k.ws == ws_bytes_avail) return k.plan;
+    if (k.M == p.M && k.N == p.N && k.K == p.K && k.epi == epi && k.big_ok == big_ok && k.ws == ws_bytes_avail) return k.plan;
   const G2Plan plan = g2_plan_search(p, cus, ws_bytes_avail);
-  if (cache.size() < 4096) cache.push_back(Key{p.M, p.N, p.K, epi, ws_bytes_avail, plan});
+  if (cache.size() < 4096) cache.push_back(Key{p.M, p.N, p.K, epi, big_ok, ws_bytes_avail, plan});
   return plan;
 }
 
@@ -1012,10 +1330,11 @@ static int g2_launch_t(const GemmParams& p, const G2Sched& s, int grid, hipStrea
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, NJ == 8 ? 163840 : G2_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8>), dim3(grid), dim3(512), G2_LDS, st, p, s);
+  // (the 256 x 256 tile takes all 160 KiB of LDS: five 32 KiB slots)
+  hipLaunchKernelGGL((gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8>), dim3(grid), dim3(512), NJ == 8 ? 163840 : G2_LDS, st, p, s);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
@@ -1047,8 +1366,9 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
     if (const char* f = getenv("MMSA_G2_NJ")) {  // test hook: "nj" (256-row tile) or "wm:nj"; the K split is still planned
       int a = 0, b = 0;
       const int n = sscanf(f, "%d:%d", &a, &b);
-      if (n == 2 && (a == 4 || a == 2) && b >= 1 && b <= (a == 4 ? 4 : 2) && !(a == 4 && b < 2)) { fwm = a; fnj = b; }
-      else if (n == 1 && a >= 2 && a <= 4) { fwm = 4; fnj = a; }
+      if (n == 2 && (a == 4 || a == 2) && b >= 1 && (b <= (a == 4 ? 4 : 2) || (a == 4 && b == 8)) && !(a == 4 && b < 2)) { fwm = a; fnj = b; }
+      else if (n == 1 && ((a >= 2 && a <= 4) || a == 8)) { fwm = 4; fnj = a; }
+      if (fnj == 8 && (p.gather || p.scale_a || p.c_gw > 0 || p.colstat || p.mul || p.add || p.a_kmajor || (p.out_f32 && p.accumulate))) { fwm = 0; fnj = 0; }  // the forced shape does not exist for this problem
     }
     plan = fwm ? g2_plan_search(p, cus, ws_bytes_avail, fwm, fnj) : g2_plan(p, cus, ws_bytes_avail);
   }
@@ -1127,13 +1447,23 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   g2_last_plan[0] = plan.wm; g2_last_plan[1] = plan.nj; g2_last_plan[2] = s.split_k;
   int rc;
   if (plan.wm == 4) {
-    if (plan.nj == 4) rc = g2_launch_nj<4, 4>(p, s, grid, st);
+    if (plan.nj == 8) {
+      if (!p.a_kmajor && !p.b_kmajor) rc = g2_launch_t<4, 8, false, false, 0>(p, s, grid, st);
+      else if (!p.a_kmajor && p.b_kmajor) rc = g2_launch_t<4, 8, false, true, 0>(p, s, grid, st);
+      else rc = MMSA_ERR_UNSUPPORTED;  // (k-major A: the planner never picks the big tile)
+    }
+#ifdef G2_ONLY_BIG  // build-time probe (-DG2_ONLY_BIG): the 256 x 256 variants alone, for a quick resource-usage report
+    else rc = MMSA_ERR_UNSUPPORTED;
+  } else rc = MMSA_ERR_UNSUPPORTED;
+#else
+    else if (plan.nj == 4) rc = g2_launch_nj<4, 4>(p, s, grid, st);
     else if (plan.nj == 3) rc = g2_launch_nj<4, 3>(p, s, grid, st);
     else rc = g2_launch_nj<4, 2>(p, s, grid, st);
   } else {
     if (plan.nj == 2) rc = g2_launch_nj<2, 2>(p, s, grid, st);
     else rc = g2_launch_nj<2, 1>(p, s, grid, st);
   }
+#endif
   if (rc) return rc;
   if (s.split_k > 1) {
     launch_splitk_reduce<bf16>(p, st);
@@ -1201,7 +1531,11 @@ int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hip
   p.a_bytes = s.grp[0].a_bytes; p.b_bytes = s.grp[0].b_bytes;
   const int grid = tiles < cus ? tiles : cus;
   g2_last_plan[0] = plan.wm; g2_last_plan[1] = plan.nj; g2_last_plan[2] = 1;
+#ifdef G2_ONLY_BIG
+  return MMSA_ERR_UNSUPPORTED;
+#else
   if (plan.nj == 4) return g2_launch_t<4, 4, true, true, 0>(p, s, grid, st);
   if (plan.nj == 3) return g2_launch_t<4, 3, true, true, 0>(p, s, grid, st);
   return g2_launch_t<4, 2, true, true, 0>(p, s, grid, st);
+#endif
 }
