@@ -323,6 +323,26 @@ def main(argv=None):
                    "gemm_tflops": round(g_tf, 2), "gemm_frac_of_peak": round(g_tf / peak, 4),
                    "gemm_ms": round(fms.value / STAMP_STEPS, 3), "gemm_launches": fn_.value // STAMP_STEPS,
                    "what": "training-mode forward of the same model and batch, no autograd; 30 passes after the timed steps"}
+    # (4) the peak restated on THIS box: CU count x sustained matrix-core clock x MFMA FLOP/CU/clk. The clock is
+    #     measured under a dense bf16 MFMA load on pseudo-random operands (mmsa_mfma_clock_probe: ~0.5 s of back-to-back launches,
+    #     s_memtime / s_memrealtime stamps of the last one); bf16 16x16x32 = 16384 FLOP per 16 cycles per SIMD = 4096 FLOP/CU/clk.
+    clock = None
+    if rank == 0 and os.environ.get("MMSA_BENCH_NOPROF", "0") == "0":
+        try:
+            cus = torch.cuda.get_device_properties(device).multi_processor_count
+            ws = torch.zeros(cus * 1040, dtype=torch.uint8, device=device)
+            L.mmsa_mfma_clock_probe(ctypes.c_void_p(ws.data_ptr()), cus, 4000, 60, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            st = ws[:cus * 16].view(torch.int64).view(cus, 2).double()
+            ghz = (st[:, 0] / st[:, 1] * 0.1).median().item()
+            mfma_tf = cus * 4 * 4000 * 16 * 16384 / (st[:, 1].median().item() * 1e-8) / 1e12  # what that loop itself delivered
+            clock = {"cus": cus, "sustained_mfma_clock_ghz": round(ghz, 3), "max_clock_ghz": round(getattr(torch.cuda.get_device_properties(device), "clock_rate", 2400000) / 1e6, 3),
+                     "peak_at_sustained_clock_tflops": round(cus * 4096 * ghz / 1e3, 1),
+                     "mfma_only_loop_tflops": round(mfma_tf, 1),
+                     "what": "dense bf16 v_mfma_f32_16x16x32 loop on pseudo-random operands, one wave per SIMD on every CU, 60 back-to-back launches; "
+                             "clock = s_memtime / s_memrealtime of the last launch (median over workgroups); 4096 FLOP/CU/clk"}
+        except Exception as e:  # the probe is a report, never a reason to lose the line
+            clock = {"error": str(e)}
     if rank == 0:
         pairs = args.batch * world * args.steps
         flop_mult = 3 if args.mode == "train" else 1
@@ -365,6 +385,10 @@ def main(argv=None):
                          "step_algorithmic_tflops_per_gpu": round(step_tflops, 2),
                          "step_frac_of_peak": round(step_tflops / peak, 4)},
         }
+        if clock is not None:
+            out["roofline"]["peak_on_this_box"] = clock
+            if clock.get("peak_at_sustained_clock_tflops") and args.precision != "fp32":
+                out["roofline"]["frac_of_peak_at_sustained_clock"] = round(gemm_tflops / clock["peak_at_sustained_clock_tflops"], 4)
         if fwd is not None:
             out["forward"] = fwd
         if loss is not None:

@@ -156,7 +156,10 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* c, const float* w32, const void* wt, cons
  * image is NCHW fp32 [batch][3][height][width] as the reference-style loaders deliver it; everything inside is NHWC
  * in the storage dtype. Convolution weights are physically [Cout][KH][KW][Cin] (channels_last of the logical
  * torchvision shape). `bnbuf` = flat fp32 running_mean / running_var buffers (param_info with buffers = 1),
- * updated in training mode. */
+ * updated in training mode. `training`: 1 = batch statistics (running buffers updated); 0 = eval mode, every tensor a backward
+ * needs is kept; 2 = inference (eval mode, forward only): each BatchNorm is folded into the convolution that feeds it — scale /
+ * shift from the running statistics applied by the GEMM epilogue with the ReLU and the residual add, no BatchNorm kernel, the
+ * pre-normalisation tensor is never stored (mmsa_resnet_bwd must not follow). */
 typedef struct mmsa_resnet_cfg {
   int32_t batch, height, width;
   int32_t blocks[4], widths[4];
@@ -311,6 +314,13 @@ int mmsa_prof_sample(int32_t stride, int32_t phase);
  * the kernel's own duration, as rocprofv3 --kernel-trace reports it. Set before mmsa_prof_begin. */
 int mmsa_prof_mode(int32_t mode);
 int mmsa_prof_end(double* total_ms, double* total_flop, int64_t* launches);
+
+/* Sustained matrix-core clock of this chip (bench.py: the peak restated from CU count x sustained clock x MFMA FLOP/CU/clk,
+ * SURVEY.md section 8(d); the reference has no counterpart). Runs `launches` back-to-back launches of a dense bf16 MFMA loop
+ * (`iters` x 16 v_mfma_f32_16x16x32_bf16 per wave, one wave per SIMD, `blocks` workgroups) and leaves, for the LAST launch,
+ * ws[2b] = shader cycles and ws[2b+1] = 100 MHz ticks of workgroup b as uint64 (ws: blocks * 1040 bytes of device memory).
+ * clock [GHz] = cycles / ticks * 0.1 after a stream synchronize. */
+int mmsa_mfma_clock_probe(void* ws, int32_t blocks, int32_t iters, int32_t launches, void* stream);
 
 #ifdef __cplusplus
 }

@@ -146,6 +146,7 @@ def _declare(L):
         "mmsa_adamw_step_dev": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, f32, vp]),
         "mmsa_cast_f32": (ctypes.c_int, [i32, vp, vp, i64, vp]),
         "mmsa_widen_bf16": (ctypes.c_int, [vp, vp, i64, vp]),
+        "mmsa_mfma_clock_probe": (ctypes.c_int, [vp, i32, i32, i32, vp]),
         "mmsa_prof_begin": (ctypes.c_int, [i32]),
         "mmsa_prof_sample": (ctypes.c_int, [i32, i32]),
         "mmsa_prof_mode": (ctypes.c_int, [i32]),

@@ -166,6 +166,25 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, con
   invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
 }
 
+// inference-mode fold: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale (the convolution GEMM's
+// epilogue then applies acc * scale + shift: no BatchNorm kernel at all in a forward-only pass)
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps, int C,
+                               float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] * (1.0f / sqrtf(running_var[c] + eps));
+  scale[c] = sc;
+  shift[c] = beta[c] - running_mean[c] * sc;
+}
+int bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
+            float* scale, float* shift, hipStream_t st) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return MMSA_ERR_ARG;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, gamma, beta, running_mean, running_var, eps, C, scale, shift);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
 // y = act( (x - mean) * invstd * gamma + beta (+ res) )
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,

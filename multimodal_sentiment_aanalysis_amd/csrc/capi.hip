@@ -156,6 +156,9 @@ int mmsa_widen_bf16(const void* src, float* dst, int64_t n, void* stream) {
   return widen_bf16(src, dst, n, (hipStream_t)stream);
 }
 
+int mmsa_mfma_clock_probe(void* ws, int32_t blocks, int32_t iters, int32_t launches, void* stream) {
+  return mfma_clock_probe(ws, blocks, iters, launches, (hipStream_t)stream);
+}
 int mmsa_prof_begin(int32_t max_records) { return gemm_prof_begin(max_records); }
 int mmsa_prof_sample(int32_t stride, int32_t phase) { return gemm_prof_sample(stride, phase); }
 int mmsa_prof_mode(int32_t mode) { return gemm_prof_mode(mode); }

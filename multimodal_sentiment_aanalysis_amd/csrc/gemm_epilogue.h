@@ -24,6 +24,7 @@ template <> struct Vec4<bf16> {
 // loads them once per column group instead of once per 16x16 tile.
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue4b(const GemmParams& p, int m, int n, f32x4 v, f32x4 bias4) {
+  if (p.col_scale) v *= *(const f32x4*)(p.col_scale + n);
   v += bias4;
   if (p.C2 && p.c2_gelu_grad) {
     f32x4 d;
@@ -32,7 +33,7 @@ __device__ __forceinline__ void gemm_epilogue4b(const GemmParams& p, int m, int 
     Vec4<T>::store((T*)p.C2 + (long)m * p.ldc2 + n, d);
   } else {
     if (p.C2) Vec4<T>::store((T*)p.C2 + (long)m * p.ldc2 + n, v);
-    if (p.act != MMSA_ACT_NONE) {
+    if (p.act != MMSA_ACT_NONE && !p.act_after_add) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
     }
@@ -43,6 +44,10 @@ __device__ __forceinline__ void gemm_epilogue4b(const GemmParams& p, int m, int 
     for (int r = 0; r < 4; ++r) v[r] *= p.mul_is_factor ? x[r] : gelu_erf_grad(x[r]);
   }
   if (p.add) v += Vec4<T>::load((const T*)p.add + (long)m * p.ldadd + n);
+  if (p.act != MMSA_ACT_NONE && p.act_after_add) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+  }
   if (p.out_f32) {
     float* c = (float*)p.C + (long)m * p.ldc + n;
     if (p.accumulate) v += *(const f32x4*)c;
@@ -54,6 +59,7 @@ __device__ __forceinline__ void gemm_epilogue4b(const GemmParams& p, int m, int 
 
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n, f32x4 v) {
+  if (p.col_scale) v *= *(const f32x4*)(p.col_scale + n);
   if (p.bias) v += *(const f32x4*)(p.bias + n);
   if (p.C2 && p.c2_gelu_grad) {
     f32x4 d;
@@ -62,7 +68,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n
     Vec4<T>::store((T*)p.C2 + (long)m * p.ldc2 + n, d);
   } else {
     if (p.C2) Vec4<T>::store((T*)p.C2 + (long)m * p.ldc2 + n, v);
-    if (p.act != MMSA_ACT_NONE) {
+    if (p.act != MMSA_ACT_NONE && !p.act_after_add) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
     }
@@ -73,6 +79,10 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n
     for (int r = 0; r < 4; ++r) v[r] *= p.mul_is_factor ? x[r] : gelu_erf_grad(x[r]);
   }
   if (p.add) v += Vec4<T>::load((const T*)p.add + (long)m * p.ldadd + n);
+  if (p.act != MMSA_ACT_NONE && p.act_after_add) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+  }
   if (p.out_f32) {
     float* c = (float*)p.C + (long)m * p.ldc + n;
     if (p.accumulate) v += *(const f32x4*)c;
@@ -85,6 +95,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n
 // scalar form for shapes whose N (or a leading dimension) is not a multiple of 4 (the 3-class heads)
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue1(const GemmParams& p, int m, int n, float v) {
+  if (p.col_scale) v *= p.col_scale[n];
   if (p.bias) v += p.bias[n];
   if (p.C2 && p.c2_gelu_grad) {
     const GeluPair gp = gelu_erf_both(v);
@@ -92,13 +103,14 @@ __device__ __forceinline__ void gemm_epilogue1(const GemmParams& p, int m, int n
     ((T*)p.C2)[(long)m * p.ldc2 + n] = from_f32<T>(gp.dy);
   } else {
     if (p.C2) ((T*)p.C2)[(long)m * p.ldc2 + n] = from_f32<T>(v);
-    if (p.act != MMSA_ACT_NONE) v = apply_act(v, p.act);
+    if (p.act != MMSA_ACT_NONE && !p.act_after_add) v = apply_act(v, p.act);
   }
   if (p.mul) {
     const float x = to_f32<T>(((const T*)p.mul)[(long)m * p.ldmul + n]);
     v *= p.mul_is_factor ? x : gelu_erf_grad(x);
   }
   if (p.add) v += to_f32<T>(((const T*)p.add)[(long)m * p.ldadd + n]);
+  if (p.act != MMSA_ACT_NONE && p.act_after_add) v = apply_act(v, p.act);
   if (p.out_f32) {
     float* c = (float*)p.C + (long)m * p.ldc + n;
     if (p.accumulate) v += *c;

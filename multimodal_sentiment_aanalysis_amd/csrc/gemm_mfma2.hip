@@ -121,7 +121,12 @@ __device__ __forceinline__ float row16_sum(float v) {
 // FP8: the operands are e4m3 bytes (NT only): a K step of 64 two-byte slots is 128 fp8 values in the SAME LDS image, every
 // 16-byte fragment read feeds two v_mfma_f32_16x16x32_fp8_fp8 (bytes 0-7, 8-15: A and B share the slot -> k assignment, so
 // every k meets its partner once), and the epilogue scales by scale_a * scale_b. Half the L2->LDS bytes per FLOP.
-template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8 = false>
+// GEN: the general epilogue (bias / activation / side output / gelu' and residual operands / fp32 read-modify-write) is compiled in.
+// Launches whose epilogue is a plain store (s.fast) or a split-K slab store take the GEN = false instantiation: the general
+// epilogue's ~60 extra live registers made the allocator spill LOOP-CARRIED values of kernels that never execute it — the grouped
+// weight-gradient kernel went from 177 to 492 us when two more arrays were added to an epilogue it does not use — and every
+// scratch reload in the K loop waits vmcnt(0), i.e. drains the LDS-DMA ring.
+template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8 = false, bool GEN = true>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) {
   // The body is compiled in the device pass only: hipcc's HOST pass (ROCm 7.2) silently fails to instantiate this
   // template when it sees the body (no diagnostic, the launch stub stays an undefined symbol of the .so).
@@ -549,6 +554,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       }
       return (p.out_f32 ? 2 : 1) * (BIG ? 2 : 1);
     }
+    if constexpr (!GEN) {  // (not reached: the launcher gives a non-plain epilogue the GEN instantiation)
+      wait_vm<0>();
+      return 0;
+    } else {
     // general epilogue (reads bias / side operands), then a full drain so the counted waits of the following steps
     // see an empty queue. All side-operand loads of the tile are issued up front, branch-free through buffer
     // descriptors (out-of-range lanes read 0), and awaited once: as a per-sub-tile load -> use -> store chain it cost
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       auto part = [&](auto j0_c) __attribute__((always_inline)) {
       constexpr int J0 = decltype(j0_c)::value;
       const long cext = (long)(p.M - 1);
-      f32x4 bias4[JW];
+      f32x4 bias4[JW], scale4[JW];
       // gelu' operand, or the residual when there is no gelu' operand (both: a second batch). The 256 x 256 tile takes no side
       // operands (the planner keeps such problems on the smaller tiles): 128 accumulators leave no room for them
       i32x2 side[BIG ? 1 : 4][BIG ? 1 : JW];
@@ -584,6 +593,14 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
         for (int j = 0; j < JW; ++j) {
           const int n = nb + (J0 + j) * 16;
           bias4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, n < p.N ? n * 4 : OOB, 0, 0));
+        }
+        if (p.col_scale) {  // a folded inference-mode BatchNorm: acc * scale[n] + shift[n] (shift rides in `bias`)
+          __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)p.col_scale, 0, p.N * 4, 0x00020000);
+#pragma unroll
+          for (int j = 0; j < JW; ++j) {
+            const int n = nb + (J0 + j) * 16;
+            scale4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsc, n < p.N ? n * 4 : OOB, 0, 0));
+          }
         }
       }
       if (has_mul) load_side(p.mul, p.ldmul);
@@ -615,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
         for (int jj = 0; jj < JW; ++jj) {
           const int j = J0 + jj;
 #pragma unroll
-          for (int h = 0; h < 2; ++h) acc[i + h][j] += bias4[jj];
+          for (int h = 0; h < 2; ++h) acc[i + h][j] = p.col_scale ? acc[i + h][j] * scale4[jj] + bias4[jj] : acc[i + h][j] + bias4[jj];
           if (p.C2 && p.c2_gelu_grad) {  // side output = gelu'(pre-activation), from the same exp / erf as the activation
             f32x4 d0, d1;
 #pragma unroll
@@ -627,7 +644,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
             store_pair(rc2, p.ldc2, mrow + i * 16, ncol + j * 16, d0, d1);
           } else {
             if (p.C2) store_pair(rc2, p.ldc2, mrow + i * 16, ncol + j * 16, acc[i][j], acc[i + 1][j]);
-            if (p.act != MMSA_ACT_NONE) {
+            if (p.act != MMSA_ACT_NONE && !p.act_after_add) {
 #pragma unroll
               for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -663,6 +680,12 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
           if (has_add) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) acc[i + h][j] += unpack(side[BIG ? 0 : i + h][BIG ? 0 : jj]);
+          }
+          if (p.act != MMSA_ACT_NONE && p.act_after_add) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[i + h][j][r] = apply_act(acc[i + h][j][r], p.act);
           }
           if (p.out_f32) {
 #pragma unroll
@@ -706,6 +729,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     }
     wait_vm<0>();
     return 0;
+    }
   };
 
   // ---- main loop. One iteration = one K step (64 deep) of the stream, in two halves of 32:
@@ -1222,7 +1246,7 @@ bool gemm2_eligible(const GemmParams& p) {
 int g2_last_plan[3] = {0, 0, 0};  // profiling only (gemm_mfma.hip): tile shape and K split of the latest launch
 
 static inline int g2_epi_class(const GemmParams& p) {
-  return (p.mul || p.add) ? 2 : (p.bias || p.C2 || p.act != MMSA_ACT_NONE || (p.out_f32 && p.accumulate)) ? 1 : 0;
+  return (p.mul || p.add) ? 2 : (p.bias || p.col_scale || p.C2 || p.act != MMSA_ACT_NONE || (p.out_f32 && p.accumulate)) ? 1 : 0;
 }
 
 struct G2Plan { int wm, nj, split; };  // wave rows (4: 256-row tile, 2: 128-row tile), column tiles per wave, K split
@@ -1325,18 +1349,24 @@ static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
   return plan;
 }
 
-template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8 = false>
-static int g2_launch_t(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
+template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8, bool GEN>
+static int g2_launch_e(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8>,
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8, GEN>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, NJ == 8 ? 163840 : G2_LDS);
     attr_set = true;
   }
   // (the 256 x 256 tile takes all 160 KiB of LDS: five 32 KiB slots)
-  hipLaunchKernelGGL((gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8>), dim3(grid), dim3(512), NJ == 8 ? 163840 : G2_LDS, st, p, s);
+  hipLaunchKernelGGL((gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8, GEN>), dim3(grid), dim3(512), NJ == 8 ? 163840 : G2_LDS, st, p, s);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
+}
+template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8 = false>
+static int g2_launch_t(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
+  // plain-store and slab-store launches: the instantiation without the general epilogue (see gemm2_kernel)
+  if (s.fast || s.split_k > 1) return g2_launch_e<WM, NJ, A_KM, B_KM, GATHER, FP8, false>(p, s, grid, st);
+  return g2_launch_e<WM, NJ, A_KM, B_KM, GATHER, FP8, true>(p, s, grid, st);
 }
 
 template <int WM, int NJ>
@@ -1411,7 +1441,7 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
       s.fd_sbc = make_fastdiv((uint32_t)(s.ntn / s.cb));
     }
   }
-  s.fast = (!p.bias && !p.C2 && p.act == MMSA_ACT_NONE && !p.mul && !p.add && !(p.out_f32 && p.accumulate)) ? 1 : 0;
+  s.fast = (!p.bias && !p.col_scale && !p.C2 && p.act == MMSA_ACT_NONE && !p.mul && !p.add && !(p.out_f32 && p.accumulate)) ? 1 : 0;
   p.split_k = s.split_k;
   s.dbg = 0;
   s.ngroups = 0;
@@ -1532,7 +1562,11 @@ int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hip
   const int grid = tiles < cus ? tiles : cus;
   g2_last_plan[0] = plan.wm; g2_last_plan[1] = plan.nj; g2_last_plan[2] = 1;
 #ifdef G2_ONLY_BIG
+#ifdef G2_ONLY_GROUP  // (-DG2_ONLY_BIG -DG2_ONLY_GROUP: the grouped 256 x 128 TN kernel alone)
+  return g2_launch_t<4, 4, true, true, 0>(p, s, grid, st);
+#else
   return MMSA_ERR_UNSUPPORTED;
+#endif
 #else
   if (plan.nj == 4) return g2_launch_t<4, 4, true, true, 0>(p, s, grid, st);
   if (plan.nj == 3) return g2_launch_t<4, 3, true, true, 0>(p, s, grid, st);

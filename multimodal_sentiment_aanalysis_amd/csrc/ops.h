@@ -47,6 +47,11 @@ int infonce_fwd_bwd(const float* feat1, const float* feat2, const long long* lab
 int supcon_fwd_bwd(const float* z1, const float* z2, const long long* labels, float temperature, float* loss, float* dz1,
                    float* dz2, int B, int D, float grad_scale, float* ws, hipStream_t st);
 
+int bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
+            float* scale, float* shift, hipStream_t st);
+// clockprobe.hip
+int mfma_clock_probe(void* ws, int blocks, int iters, int launches, hipStream_t st);
+
 // bnops.hip
 size_t bn_ws_bytes(int C);
 int bn_forward(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,

@@ -195,14 +195,26 @@ static bool conv_stats_on() {
   return !(v && atoi(v) != 0);
 }
 // z[B*Ho*Wo][Cout] = conv(x)
-static int conv_fwd(const ResCtx& r, const ConvDef& c, const void* x, void* z, ConvStats* cs = nullptr) {
+// fold (inference): scale / shift of the folded BatchNorm, activation, residual: y = act(conv(x) * scale + shift (+ res))
+struct ConvFold {
+  const float* scale;
+  const float* shift;
+  int act;
+  const void* res;
+};
+static int conv_fwd(const ResCtx& r, const ConvDef& c, const void* x, void* z, ConvStats* cs = nullptr,
+                    const ConvFold* fold = nullptr) {
   const int B = r.c.batch, M = B * c.Hout * c.Wout, K = c.k * c.k * c.Cin;
   GemmParams p = Eng::blank();
   p.A = x; p.lda = c.Cin; p.B = r.W(c.w); p.ldb = K; p.C = z; p.ldc = c.Cout;
   p.M = M; p.N = c.Cout; p.K = K;
+  if (fold) {
+    p.col_scale = fold->scale; p.bias = fold->shift; p.act = fold->act; p.add = fold->res; p.ldadd = c.Cout;
+    p.act_after_add = fold->res ? 1 : 0;
+  }
   if (cs) {
     cs->rows = 0;
-    if (r.c.training && r.c.dtype == MMSA_BF16 && conv_stats_on()) { p.colstat = cs->part; p.colstat_cap = cs->cap; p.colstat_rows = &cs->rows; }
+    if (r.c.training == 1 && r.c.dtype == MMSA_BF16 && conv_stats_on()) { p.colstat = cs->part; p.colstat_cap = cs->cap; p.colstat_rows = &cs->rows; }
   }
   if (!(c.k == 1 && c.stride == 1)) {
     p.gather = 1;
@@ -307,7 +319,7 @@ static int bn_fwd(const ResCtx& r, const ConvDef& c, const ConvWs& w, const void
                   const ConvStats* cs = nullptr) {
   const int M = r.c.batch * c.Hout * c.Wout;
   return bn_forward(r.c.dtype, w.z, r.P(c.g), r.P(c.b), r.bnbuf + c.rm, r.bnbuf + c.rv, w.mean, w.invstd, res, y, bnws, M,
-                    c.Cout, r.c.bn_eps, r.c.bn_momentum, act, r.c.training, r.e.st, bn_mask(w, act),
+                    c.Cout, r.c.bn_eps, r.c.bn_momentum, act, r.c.training == 1, r.e.st, bn_mask(w, act),
                     cs && cs->rows > 0 ? cs->part : nullptr, cs ? cs->rows : 0);
 }
 // param_grads = false (a wholly frozen bottleneck): only the data gradient is produced, dgamma / dbeta are not written
@@ -315,7 +327,7 @@ static int bn_bwd(const ResCtx& r, const ConvDef& c, const ConvWs& w, const void
                   int act, float* bnws, bool param_grads = true) {
   const int M = r.c.batch * c.Hout * c.Wout;
   return bn_backward(r.c.dtype, dy, w.z, y, w.mean, w.invstd, r.P(c.g), r.P(c.b), dz, dres, param_grads ? r.G(c.g) : nullptr,
-                     param_grads ? r.G(c.b) : nullptr, r.acc, bnws, M, c.Cout, act, r.c.training, r.e.st, bn_mask(w, act));
+                     param_grads ? r.G(c.b) : nullptr, r.acc, bnws, M, c.Cout, act, r.c.training == 1, r.e.st, bn_mask(w, act));
 }
 
 extern "C" {
@@ -386,12 +398,54 @@ int mmsa_resnet_fwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
   RET_IF(pad_rows(c.dtype, w32 + s.w, ws.stem_w, 64, 147, L.Kstem_pad, st));
   // every convolution's GEMM also sums the columns of the z it stores (per 64-row slice, into the BatchNorm scratch), so the
   // BatchNorm that follows starts at its finalize: one streamed pass over z less per convolution
+  // training == 2 (inference: eval mode, forward only): every BatchNorm is FOLDED into the convolution GEMM that feeds it
+  // (conv + BN + ReLU (+ residual) = one MFMA-tiled kernel, no BatchNorm launch, z never stored): scale / shift per channel from
+  // the running statistics by one tiny kernel per convolution, applied by the GEMM epilogue (GemmParams::col_scale).
+  // MMSA_NO_BN_FOLD=1: the unfolded eval path (A/B hook).
+  const bool infer = c.training == 2 && !(getenv("MMSA_NO_BN_FOLD") && atoi(getenv("MMSA_NO_BN_FOLD")) != 0);
+  auto fold_of = [&](const ConvDef& cd, const ConvWs& cw, int act, const void* res, ConvFold* f) -> int {
+    RET_IF(bn_fold(r.P(cd.g), r.P(cd.b), bnbuf + cd.rm, bnbuf + cd.rv, c.bn_eps, cd.Cout, cw.invstd, cw.mean, st));
+    f->scale = cw.invstd; f->shift = cw.mean; f->act = act; f->res = res;
+    return MMSA_OK;
+  };
+  if (infer) {
+    ConvFold f;
+    RET_IF(fold_of(s, ws.stem, MMSA_ACT_RELU, nullptr, &f));
+    GemmParams p = Eng::blank();
+    p.A = ws.col; p.lda = L.Kstem_pad; p.B = ws.stem_w; p.ldb = L.Kstem_pad; p.C = ws.stem.y; p.ldc = 64;
+    p.M = M0; p.N = 64; p.K = L.Kstem_pad;
+    p.col_scale = f.scale; p.bias = f.shift; p.act = f.act;
+    RET_IF(r.e.gemm(p));
+    RET_IF(maxpool_fwd(c.dtype, ws.stem.y, ws.pool, ws.pool_idx, B, s.Hout, s.Wout, 64, st));
+    const void* x = ws.pool;
+    for (size_t i = 0; i < L.blocks.size(); ++i) {
+      const BlockDef& bd = L.blocks[i];
+      BlockWs& bw = ws.blocks[i];
+      const void* idn = x;
+      if (bd.has_ds) {
+        RET_IF(fold_of(bd.ds, bw.ds, MMSA_ACT_NONE, nullptr, &f));
+        RET_IF(conv_fwd(r, bd.ds, x, bw.ds.y, nullptr, &f));
+        idn = bw.ds.y;
+      }
+      RET_IF(fold_of(bd.c1, bw.c1, MMSA_ACT_RELU, nullptr, &f));
+      RET_IF(conv_fwd(r, bd.c1, x, bw.c1.y, nullptr, &f));
+      RET_IF(fold_of(bd.c2, bw.c2, MMSA_ACT_RELU, nullptr, &f));
+      RET_IF(conv_fwd(r, bd.c2, bw.c1.y, bw.c2.y, nullptr, &f));
+      RET_IF(fold_of(bd.c3, bw.c3, MMSA_ACT_RELU, idn, &f));
+      RET_IF(conv_fwd(r, bd.c3, bw.c2.y, bw.c3.y, nullptr, &f));
+      x = bw.c3.y;
+    }
+    RET_IF(avgpool_fwd(c.dtype, x, ws.pooled, B, L.Hf * L.Wf, L.feat_c, st));
+    RET_IF(r.e.linear_fwd(ws.pooled, L.feat_c, r.W(L.wproj), r.P(L.bproj), feat, c.out_dim, B, c.out_dim, L.feat_c,
+                          MMSA_ACT_NONE, nullptr, nullptr, 0, 1));
+    return MMSA_OK;
+  }
   ConvStats cs{ws.bnws, ws.bnws_floats, 0};
   {
     GemmParams p = Eng::blank();
     p.A = ws.col; p.lda = L.Kstem_pad; p.B = ws.stem_w; p.ldb = L.Kstem_pad; p.C = ws.stem.z; p.ldc = 64;
     p.M = M0; p.N = 64; p.K = L.Kstem_pad;
-    if (c.training && c.dtype == MMSA_BF16 && conv_stats_on()) { p.colstat = cs.part; p.colstat_cap = cs.cap; p.colstat_rows = &cs.rows; }
+    if (c.training == 1 && c.dtype == MMSA_BF16 && conv_stats_on()) { p.colstat = cs.part; p.colstat_cap = cs.cap; p.colstat_rows = &cs.rows; }
     RET_IF(r.e.gemm(p));
   }
   RET_IF(bn_fwd(r, s, ws.stem, nullptr, ws.stem.y, MMSA_ACT_RELU, ws.bnws, &cs));

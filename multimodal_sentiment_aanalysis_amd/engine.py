@@ -424,7 +424,10 @@ class _ResnetFn(torch.autograd.Function):
     def forward(ctx, eng, dummy, image):
         L = _lib.load()
         B, C, H, W = image.shape
-        cfg = _resnet_cfg(eng.config, B, H, W, eng.out_dim, eng._storage_code(), eng.training)
+        # training: 1 = batch statistics; 0 = eval with everything kept for a backward; 2 = inference (eval, no backward will
+        # follow): every BatchNorm folded into its convolution's GEMM epilogue (conv + BN + ReLU (+ residual) as one kernel)
+        mode = 1 if eng.training else (2 if dummy is None else 0)
+        cfg = _resnet_cfg(eng.config, B, H, W, eng.out_dim, eng._storage_code(), mode)
         nbytes = L.mmsa_resnet_ws_bytes(ctypes.byref(cfg))
         if nbytes == 0 or C != 3:
             raise MmsaError(f"unsupported ResNet input {tuple(image.shape)}")
