@@ -157,9 +157,10 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* c, const float* w32, const void* wt, cons
  * in the storage dtype. Convolution weights are physically [Cout][KH][KW][Cin] (channels_last of the logical
  * torchvision shape). `bnbuf` = flat fp32 running_mean / running_var buffers (param_info with buffers = 1),
  * updated in training mode. `training`: 1 = batch statistics (running buffers updated); 0 = eval mode, every tensor a backward
- * needs is kept; 2 = inference (eval mode, forward only): each BatchNorm is folded into the convolution that feeds it — scale /
- * shift from the running statistics applied by the GEMM epilogue with the ReLU and the residual add, no BatchNorm kernel, the
- * pre-normalisation tensor is never stored (mmsa_resnet_bwd must not follow). */
+ * needs is kept; 2 = inference (eval mode, forward only): each BatchNorm is folded into the convolution that feeds it — the
+ * scale gamma / sqrt(running_var + eps) goes into a scratch copy of the weights, the shift into the GEMM's bias, the ReLU and the
+ * residual add into its epilogue: no BatchNorm kernel, the pre-normalisation tensor is never stored (mmsa_resnet_bwd must not
+ * follow). */
 typedef struct mmsa_resnet_cfg {
   int32_t batch, height, width;
   int32_t blocks[4], widths[4];

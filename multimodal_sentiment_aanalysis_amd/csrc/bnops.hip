@@ -166,8 +166,8 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, con
   invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
 }
 
-// inference-mode fold: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale (the convolution GEMM's
-// epilogue then applies acc * scale + shift: no BatchNorm kernel at all in a forward-only pass)
+// inference-mode fold: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale (the scale goes into the
+// convolution's weights, the shift into its bias: no BatchNorm kernel at all in a forward-only pass)
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps, int C,
                                float* __restrict__ scale, float* __restrict__ shift) {
@@ -177,10 +177,24 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
   scale[c] = sc;
   shift[c] = beta[c] - running_mean[c] * sc;
 }
-int bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
-            float* scale, float* shift, hipStream_t st) {
-  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return MMSA_ERR_ARG;
+// w'[o][k] = w[o][k] * scale[o] (fp32 master weights in, storage type out): fold-then-convolve, the classic inference form
+template <typename T>
+__global__ __launch_bounds__(256) void bn_fold_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                              T* __restrict__ out, int rows, int K, int ld_out) {
+  const int o = blockIdx.x;
+  const float sc = scale[o];
+  for (int k = threadIdx.x; k < K; k += 256) out[(long)o * ld_out + k] = from_f32<T>(w[(long)o * K + k] * sc);
+}
+// scale / shift of an inference-mode BatchNorm and the convolution weights with the scale folded in: conv(x, w) * scale + shift =
+// conv(x, w') + shift. `w` [rows][K] fp32, `wout` [rows][ld_out] in the storage type (ld_out >= K: the stem's zero-padded K).
+int bn_fold(int dtype, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+            int C, float* scale, float* shift, const float* w, void* wout, int K, int ld_out, hipStream_t st) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || !w || !wout || C <= 0 || K <= 0) return MMSA_ERR_ARG;
   hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, gamma, beta, running_mean, running_var, eps, C, scale, shift);
+  if (dtype == MMSA_BF16)
+    hipLaunchKernelGGL(bn_fold_weights_kernel<bf16>, dim3(C), dim3(256), 0, st, w, (const float*)scale, (bf16*)wout, C, K, ld_out);
+  else
+    hipLaunchKernelGGL(bn_fold_weights_kernel<float>, dim3(C), dim3(256), 0, st, w, (const float*)scale, (float*)wout, C, K, ld_out);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }

@@ -24,11 +24,14 @@ __global__ __launch_bounds__(256) void mfma_clock_probe_kernel(int iters, unsign
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = cp_f32x4{0.f, 0.f, 0.f, 0.f};
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-#pragma unroll 4
+  // inline asm with the accumulator as an in-place operand: written with the builtin, hipcc rotated the loop-carried accumulators
+  // through v_accvgpr moves (a read-after-MFMA stall in every iteration: the "bare" loop then measured the copies, not the pipe)
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k >> 2], b[k & 3], acc[k], 0, 0, 0);
+    for (int k = 0; k < 16; ++k)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[k]) : "v"(a[k >> 2]), "v"(b[k & 3]));
   }
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // MFMA result -> VALU read: the wait states hipcc would have inserted itself
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   cp_f32x4 s = acc[0];
 #pragma unroll

@@ -45,7 +45,7 @@ struct GemmParams {
   long b_tap_stride;
   long b_tap_stride_y;    // element stride of a tap row (0: KW * b_tap_stride); tap (ky, kx) sits at ky * this + kx * b_tap_stride
   ConvGeom g;
-  // epilogue: v = acc (* col_scale[n]) (+ bias[n]); C2 = v (optional, storage type); v = act(v); v *= gelu'(mul[m][n]) (optional);
+  // epilogue: v = acc (+ bias[n]); C2 = v (optional, storage type); v = act(v); v *= gelu'(mul[m][n]) (optional);
   //           v += add[m][n] (optional); (v = act(v) here instead when act_after_add;) C = v (storage type, or fp32 when out_f32;
   //           += when accumulate)
   const float* bias;
@@ -56,10 +56,8 @@ struct GemmParams {
   long ldmul;
   const void* add;
   long ldadd;
-  // col_scale (optional, [N] fp32): v = acc * col_scale[n] (+ bias[n]) — a BatchNorm in inference mode folded into the convolution
-  // that feeds it (scale = gamma / sqrt(running_var + eps), bias = beta - running_mean * scale). act_after_add: the activation is
-  // applied AFTER `add` (a bottleneck's output is relu(bn3(conv3) + identity)) instead of before it.
-  const float* col_scale;
+  // act_after_add: the activation is applied AFTER `add` (a bottleneck's output in inference mode, with its BatchNorm folded into
+  // the convolution's weights and bias, is relu(conv3'(x) + b' + identity)) instead of before it.
   int act_after_add;
   // engine-internal variants of the two GELU operands (0 = the documented forms): c2_gelu_grad: C2 receives gelu'(v)
   // instead of v (act must be GELU); mul_is_factor: `mul` already holds that factor (v *= mul, no gelu' evaluation).

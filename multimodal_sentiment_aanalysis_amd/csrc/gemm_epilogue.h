@@ -24,7 +24,6 @@ template <> struct Vec4<bf16> {
 // loads them once per column group instead of once per 16x16 tile.
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue4b(const GemmParams& p, int m, int n, f32x4 v, f32x4 bias4) {
-  if (p.col_scale) v *= *(const f32x4*)(p.col_scale + n);
   v += bias4;
   if (p.C2 && p.c2_gelu_grad) {
     f32x4 d;
@@ -59,7 +58,6 @@ __device__ __forceinline__ void gemm_epilogue4b(const GemmParams& p, int m, int 
 
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n, f32x4 v) {
-  if (p.col_scale) v *= *(const f32x4*)(p.col_scale + n);
   if (p.bias) v += *(const f32x4*)(p.bias + n);
   if (p.C2 && p.c2_gelu_grad) {
     f32x4 d;
@@ -95,7 +93,6 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n
 // scalar form for shapes whose N (or a leading dimension) is not a multiple of 4 (the 3-class heads)
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue1(const GemmParams& p, int m, int n, float v) {
-  if (p.col_scale) v *= p.col_scale[n];
   if (p.bias) v += p.bias[n];
   if (p.C2 && p.c2_gelu_grad) {
     const GeluPair gp = gelu_erf_both(v);

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     bias4[j] = (p.bias && p.split_k <= 1 && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // fast path: plain bf16 store (+ bias) — most launches (dgrads, convolutions) — without the option branches
-  if (p.split_k <= 1 && !p.C2 && p.act == MMSA_ACT_NONE && !p.mul && !p.add && !p.out_f32 && !p.col_scale) {
+  if (p.split_k <= 1 && !p.C2 && p.act == MMSA_ACT_NONE && !p.mul && !p.add && !p.out_f32) {
     bf16* Cb = (bf16*)p.C;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       auto part = [&](auto j0_c) __attribute__((always_inline)) {
       constexpr int J0 = decltype(j0_c)::value;
       const long cext = (long)(p.M - 1);
-      f32x4 bias4[JW], scale4[JW];
+      f32x4 bias4[JW];
       // gelu' operand, or the residual when there is no gelu' operand (both: a second batch). The 256 x 256 tile takes no side
       // operands (the planner keeps such problems on the smaller tiles): 128 accumulators leave no room for them
       i32x2 side[BIG ? 1 : 4][BIG ? 1 : JW];
@@ -593,14 +593,6 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
         for (int j = 0; j < JW; ++j) {
           const int n = nb + (J0 + j) * 16;
           bias4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, n < p.N ? n * 4 : OOB, 0, 0));
-        }
-        if (p.col_scale) {  // a folded inference-mode BatchNorm: acc * scale[n] + shift[n] (shift rides in `bias`)
-          __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)p.col_scale, 0, p.N * 4, 0x00020000);
-#pragma unroll
-          for (int j = 0; j < JW; ++j) {
-            const int n = nb + (J0 + j) * 16;
-            scale4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsc, n < p.N ? n * 4 : OOB, 0, 0));
-          }
         }
       }
       if (has_mul) load_side(p.mul, p.ldmul);
@@ -632,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
         for (int jj = 0; jj < JW; ++jj) {
           const int j = J0 + jj;
 #pragma unroll
-          for (int h = 0; h < 2; ++h) acc[i + h][j] = p.col_scale ? acc[i + h][j] * scale4[jj] + bias4[jj] : acc[i + h][j] + bias4[jj];
+          for (int h = 0; h < 2; ++h) acc[i + h][j] += bias4[jj];
           if (p.C2 && p.c2_gelu_grad) {  // side output = gelu'(pre-activation), from the same exp / erf as the activation
             f32x4 d0, d1;
 #pragma unroll
@@ -1246,7 +1238,7 @@ bool gemm2_eligible(const GemmParams& p) {
 int g2_last_plan[3] = {0, 0, 0};  // profiling only (gemm_mfma.hip): tile shape and K split of the latest launch
 
 static inline int g2_epi_class(const GemmParams& p) {
-  return (p.mul || p.add) ? 2 : (p.bias || p.col_scale || p.C2 || p.act != MMSA_ACT_NONE || (p.out_f32 && p.accumulate)) ? 1 : 0;
+  return (p.mul || p.add) ? 2 : (p.bias || p.C2 || p.act != MMSA_ACT_NONE || (p.out_f32 && p.accumulate)) ? 1 : 0;
 }
 
 struct G2Plan { int wm, nj, split; };  // wave rows (4: 256-row tile, 2: 128-row tile), column tiles per wave, K split
@@ -1441,7 +1433,7 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
       s.fd_sbc = make_fastdiv((uint32_t)(s.ntn / s.cb));
     }
   }
-  s.fast = (!p.bias && !p.col_scale && !p.C2 && p.act == MMSA_ACT_NONE && !p.mul && !p.add && !(p.out_f32 && p.accumulate)) ? 1 : 0;
+  s.fast = (!p.bias && !p.C2 && p.act == MMSA_ACT_NONE && !p.mul && !p.add && !(p.out_f32 && p.accumulate)) ? 1 : 0;
   p.split_k = s.split_k;
   s.dbg = 0;
   s.ngroups = 0;

@@ -47,8 +47,8 @@ int infonce_fwd_bwd(const float* feat1, const float* feat2, const long long* lab
 int supcon_fwd_bwd(const float* z1, const float* z2, const long long* labels, float temperature, float* loss, float* dz1,
                    float* dz2, int B, int D, float grad_scale, float* ws, hipStream_t st);
 
-int bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
-            float* scale, float* shift, hipStream_t st);
+int bn_fold(int dtype, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+            int C, float* scale, float* shift, const float* w, void* wout, int K, int ld_out, hipStream_t st);
 // clockprobe.hip
 int mfma_clock_probe(void* ws, int blocks, int iters, int launches, hipStream_t st);
 

@@ -94,6 +94,7 @@ struct ResWs {
   std::vector<BlockWs> blocks;
   void *pooled, *dfeat_t, *dpooled;
   void *g0, *g1, *g2, *g3;  // gradient ping-pong buffers (largest activation size)
+  void* foldw;  // inference: one convolution's weights with its BatchNorm scale folded in (largest weight)
   float *stem_dw, *splitk, *colws, *bnws;
   long bnws_floats;  // capacity of the partial-sum part of bnws (conv-epilogue statistics: GemmParams::colstat_cap)
   size_t splitk_bytes;
@@ -152,6 +153,7 @@ static ResWs res_ws(const mmsa_resnet_cfg& c, const ResLayout& L, void* base) {
   w.g2 = b.take(maxact * es);
   w.g3 = b.take(maxact * es);
   w.stem_dw = (float*)b.take((size_t)64 * L.Kstem_pad * 4);
+  w.foldw = b.take(maxw * es);
   // split-K slabs for the weight gradients: up to 64 slabs of the small early-stage weights, fewer of the large ones
   w.splitk_bytes = (size_t)16 * maxw * sizeof(float);
   w.splitk = (float*)b.take(w.splitk_bytes);
@@ -195,9 +197,10 @@ static bool conv_stats_on() {
   return !(v && atoi(v) != 0);
 }
 // z[B*Ho*Wo][Cout] = conv(x)
-// fold (inference): scale / shift of the folded BatchNorm, activation, residual: y = act(conv(x) * scale + shift (+ res))
+// fold (inference): the convolution's weights with the BatchNorm scale folded in, its shift as the bias, activation, residual:
+// y = act(conv(x, w') + shift (+ res))
 struct ConvFold {
-  const float* scale;
+  const void* w;
   const float* shift;
   int act;
   const void* res;
@@ -209,7 +212,7 @@ static int conv_fwd(const ResCtx& r, const ConvDef& c, const void* x, void* z, C
   p.A = x; p.lda = c.Cin; p.B = r.W(c.w); p.ldb = K; p.C = z; p.ldc = c.Cout;
   p.M = M; p.N = c.Cout; p.K = K;
   if (fold) {
-    p.col_scale = fold->scale; p.bias = fold->shift; p.act = fold->act; p.add = fold->res; p.ldadd = c.Cout;
+    p.B = fold->w; p.bias = fold->shift; p.act = fold->act; p.add = fold->res; p.ldadd = c.Cout;
     p.act_after_add = fold->res ? 1 : 0;
   }
   if (cs) {
@@ -398,23 +401,28 @@ int mmsa_resnet_fwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
   RET_IF(pad_rows(c.dtype, w32 + s.w, ws.stem_w, 64, 147, L.Kstem_pad, st));
   // every convolution's GEMM also sums the columns of the z it stores (per 64-row slice, into the BatchNorm scratch), so the
   // BatchNorm that follows starts at its finalize: one streamed pass over z less per convolution
-  // training == 2 (inference: eval mode, forward only): every BatchNorm is FOLDED into the convolution GEMM that feeds it
-  // (conv + BN + ReLU (+ residual) = one MFMA-tiled kernel, no BatchNorm launch, z never stored): scale / shift per channel from
-  // the running statistics by one tiny kernel per convolution, applied by the GEMM epilogue (GemmParams::col_scale).
+  // training == 2 (inference: eval mode, forward only): every BatchNorm is FOLDED into the convolution that feeds it
+  // (conv + BN + ReLU (+ residual) = one MFMA-tiled kernel, no BatchNorm launch, z never stored): per convolution two tiny
+  // kernels turn the running statistics into scale / shift and write w' = w * scale[cout] (from the fp32 master weights) into a
+  // scratch weight buffer; the GEMM runs on w' with the shift as its bias, the ReLU and the residual add in its epilogue.
   // MMSA_NO_BN_FOLD=1: the unfolded eval path (A/B hook).
   const bool infer = c.training == 2 && !(getenv("MMSA_NO_BN_FOLD") && atoi(getenv("MMSA_NO_BN_FOLD")) != 0);
   auto fold_of = [&](const ConvDef& cd, const ConvWs& cw, int act, const void* res, ConvFold* f) -> int {
-    RET_IF(bn_fold(r.P(cd.g), r.P(cd.b), bnbuf + cd.rm, bnbuf + cd.rv, c.bn_eps, cd.Cout, cw.invstd, cw.mean, st));
-    f->scale = cw.invstd; f->shift = cw.mean; f->act = act; f->res = res;
+    const int K = cd.k * cd.k * cd.Cin;
+    RET_IF(bn_fold(c.dtype, r.P(cd.g), r.P(cd.b), bnbuf + cd.rm, bnbuf + cd.rv, c.bn_eps, cd.Cout, cw.invstd, cw.mean,
+                   w32 + cd.w, ws.foldw, K, K, st));
+    f->w = ws.foldw; f->shift = cw.mean; f->act = act; f->res = res;
     return MMSA_OK;
   };
   if (infer) {
     ConvFold f;
-    RET_IF(fold_of(s, ws.stem, MMSA_ACT_RELU, nullptr, &f));
+    // the stem's weight copy is zero-padded to K = 192: fold into it in place of pad_rows' plain copy (the pad columns stay zero)
+    RET_IF(bn_fold(c.dtype, r.P(s.g), r.P(s.b), bnbuf + s.rm, bnbuf + s.rv, c.bn_eps, 64, ws.stem.invstd, ws.stem.mean, w32 + s.w,
+                   ws.stem_w, 147, L.Kstem_pad, st));
     GemmParams p = Eng::blank();
     p.A = ws.col; p.lda = L.Kstem_pad; p.B = ws.stem_w; p.ldb = L.Kstem_pad; p.C = ws.stem.y; p.ldc = 64;
     p.M = M0; p.N = 64; p.K = L.Kstem_pad;
-    p.col_scale = f.scale; p.bias = f.shift; p.act = f.act;
+    p.bias = ws.stem.mean; p.act = MMSA_ACT_RELU;
     RET_IF(r.e.gemm(p));
     RET_IF(maxpool_fwd(c.dtype, ws.stem.y, ws.pool, ws.pool_idx, B, s.Hout, s.Wout, 64, st));
     const void* x = ws.pool;
