@@ -233,4 +233,9 @@ class MultimodalTransformerModel(HeadEngine):
             return logits, outs[2], c[0], c[1], c[2]
         if labels is None:
             return logits
-        return logits, torch.zeros(1, device=logits.device)
+        # aux loss of the Trainer contract (Trainer.py:60,86: `.item()` is called on it): no contrastive term here, a constant zero
+        # kept on the device instead of a torch.zeros launch per step
+        z = getattr(self, "_zero_aux", None)
+        if z is None or z.device != logits.device:
+            z = self._zero_aux = torch.zeros(1, device=logits.device)
+        return logits, z

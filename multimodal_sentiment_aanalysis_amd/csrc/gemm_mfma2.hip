@@ -1311,7 +1311,9 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
     // the register-only epilogue costs ~1 us per item, the one with side operands one memory round trip more; on the
     // 256x128 tile both run out of registers (accumulators + side operands + the loop's prefetched fragments: the
     // compiler spills ~60 VGPRs there), measured +3 / +8 us per item (tools/microbench/bench_small.py, bench_epi2.py)
-    static const double epi_cost[3][6] = {{0, 0, 0, 0, 0, 0}, {3.0, 1.0, 0.9, 0.65, 0.5, 4.0}, {8.0, 2.0, 1.2, 1.0, 0.8, 10.0}};
+    // (r3, tools/microbench/bench_epi2.py on 8192x3072x768: bias + GELU + side output 94.8 us on the 256x128 tile against 82.0 on
+    //  256x96, bias alone 65.7 / 57.9 — the 128-wide general epilogue is the one that spills; its price went up accordingly)
+    static const double epi_cost[3][6] = {{0, 0, 0, 0, 0, 0}, {6.0, 1.0, 0.9, 0.65, 0.5, 4.0}, {12.0, 2.0, 1.2, 1.0, 0.8, 10.0}};
     static const bool no_epi = [] { const char* v = getenv("MMSA_G2_NOEPI"); return v && atoi(v) != 0; }();  // A/B hook
     const double waste = (double)ntn * bn / p.N * ((double)ntm * bm / p.M);  // padding: only as a tie breaker
     for (int c = 0; c < nc; ++c) {
@@ -1475,6 +1477,9 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
       else rc = MMSA_ERR_UNSUPPORTED;  // (k-major A: the planner never picks the big tile)
     }
 #ifdef G2_ONLY_BIG  // build-time probe (-DG2_ONLY_BIG): the 256 x 256 variants alone, for a quick resource-usage report
+#ifdef G2_ONLY_NT44   // (+ the 256 x 128 NT kernel with the general epilogue)
+    else if (plan.nj == 4) rc = g2_launch_e<4, 4, false, false, 0, false, true>(p, s, grid, st);
+#endif
     else rc = MMSA_ERR_UNSUPPORTED;
   } else rc = MMSA_ERR_UNSUPPORTED;
 #else
