@@ -31,13 +31,10 @@ FWD_GFLOP_PER_PAIR = 30.52  # BERT-base S=128 22.348 + ResNet-
 C3_FWD_GFLOP_PER_PAIR = 176.66  # BERT-large S=256 161.06 + ResNet-101 15.60
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_FP32_TFLOPS = 157.3    # fp32 matrix / vector peak (precision="fp32": exact-fp32 kernels)
-# Algorithmic HBM bytes of an average MFMA GEMM launch of this step (284 launches per step — the four weight and two bias
-# gradients of a BERT layer are one launch, a stride-2 3x3 data gradient is four — ~20.6 GFLOP each on average): every
-# distinct operand of a launch read once (a 3x3 implicit-GEMM gather counts each source pixel once), C written once (fp32
-# for weight gradients): 16.73 GB per step over the per-shape table (profiles/r01_gemm_shapes.csv) + 67 MB for the
-# parity classes' re-reads of dY = 16.80 GB / 284.
-ALG_BYTES_PER_GEMM_LAUNCH = 59.15e6
-TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+# Algorithmic HBM bytes per MFMA GEMM launch are counted by the library itself for the launches of the roofline pass
+# (mmsa_prof_last_bytes: every distinct operand of a problem read once — a 3x3 implicit-GEMM gather counts each source pixel once —
+# the output written once, epilogue side operands and side outputs included) and divided by the launch count of the same pass.
+TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def parse_args(argv=None):
@@ -276,6 +273,7 @@ def main(argv=None):
     ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     ms_ev, fl_ev, n_ev = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     fwd = None
+    alg_bytes_per_launch = None
     if os.environ.get("MMSA_BENCH_NOPROF", "0") == "0":
         L.mmsa_prof_mode(0)
         L.mmsa_prof_begin(psteps * 2400)
@@ -293,6 +291,7 @@ def main(argv=None):
         sync()
         dump = os.environ.get("MMSA_PROF_DUMP")  # per-launch shape table: <path> for this pass, <path>.fwd.csv for the forward pass
         L.mmsa_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+        alg_bytes_per_launch = L.mmsa_prof_last_bytes() / n.value if n.value else None
         if dump:
             os.environ["MMSA_PROF_DUMP"] = dump + ".fwd.csv"
         L.mmsa_prof_mode(0)
@@ -377,7 +376,7 @@ def main(argv=None):
                          "note": "value / ms_per_step = the FIRST region after the warm-up (max over ranks)"},
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_GEMM_LAUNCH if traffic is not None else None,
+                         "algorithmic_bytes_per_launch": round(alg_bytes_per_launch) if alg_bytes_per_launch else None,
                          "kernel": "every matrix-core GEMM launch (gemm2_kernel + split-K reducer; precision fp32: the "
                                    "fp32-MFMA kernel) of 3 steps right after the timed steps, averaged per step (NT/NN/TN, "
                                    "implicit-GEMM convolutions, grouped weight gradients); duration = in-kernel clock, "

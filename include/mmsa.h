@@ -96,11 +96,19 @@ typedef struct mmsa_gemm_desc {
 
 size_t mmsa_gemm_ws_bytes(int32_t M, int32_t N, int32_t split_k);
 int mmsa_gemm(const mmsa_gemm_desc* d, int32_t impl, void* stream);
-/* n (2..4) independent weight-gradient GEMMs with the same K as ONE launch of the bf16 MFMA kernel: every descriptor must
+/* n (2..12) independent weight-gradient GEMMs with the same K as ONE launch of the bf16 MFMA kernel: every descriptor must
  * have a_kmajor = b_kmajor = 1, out_f32 = 1, no epilogue operands, no split. This is how the backward of a BERT layer
  * issues its four dW = dY^T X products (the `.backward()` of the reference's train step, Trainer.py:79, reaches them
  * through autograd). Returns MMSA_ERR_UNSUPPORTED (3) when the problems cannot be grouped; nothing is launched then. */
 int mmsa_gemm_group(const mmsa_gemm_desc* d, int32_t n, void* stream);
+/* The same with a K split common to the group, planned by the library inside `ws` (device scratch for the fp32 slabs; the split
+ * is the largest useful one that fits ws_bytes): the tiles of all problems store slabs and ONE reducer launch sums them into the
+ * outputs (accumulate = 1 in every descriptor: C += instead of C =). Besides plain problems the group may be the weight
+ * gradients of convolutions with ONE geometry (gather = 2 and identical M, N, lda, ldb, geom in every descriptor; only the
+ * pointers differ). This is how the ResNet backward issues the 5-11 same-size 1x1 and the 2-5 same-geometry 3x3 weight gradients
+ * of a stage (autograd reaches them from Trainer.py:79's `.backward()`): launched one by one each needed 16-60 K slices of 4-13
+ * K steps to fill 256 CUs. Returns MMSA_ERR_UNSUPPORTED (3) when the problems cannot be grouped; nothing is launched then. */
+int mmsa_gemm_group_split(const mmsa_gemm_desc* d, int32_t n, float* ws, size_t ws_bytes, void* stream);
 /* fp8 (OCP e4m3, the gfx950 format) path of BASELINE.json configs[4]: mmsa_fp8_quantize turns a contiguous bf16 tensor (n % 8 == 0)
  * into e4m3 bytes with a per-tensor scale = amax / 448 (device float; amax_ws: mmsa_fp8_quantize_ws_bytes() of device scratch); mmsa_gemm_fp8 is the
  * NT GEMM of mmsa_gemm on such operands (desc->A / B: e4m3 bytes, k-contiguous rows, lda / ldb in bytes; K % 128 == 0, no
@@ -315,6 +323,9 @@ int mmsa_prof_sample(int32_t stride, int32_t phase);
  * the kernel's own duration, as rocprofv3 --kernel-trace reports it. Set before mmsa_prof_begin. */
 int mmsa_prof_mode(int32_t mode);
 int mmsa_prof_end(double* total_ms, double* total_flop, int64_t* launches);
+/* Algorithmic HBM bytes of the launches the latest mmsa_prof_end summed: per problem every distinct operand read once (an
+ * implicit-GEMM gather counts each source pixel once), the output written once, epilogue side operands / side outputs included. */
+double mmsa_prof_last_bytes(void);
 
 /* Sustained matrix-core clock of this chip (bench.py: the peak restated from CU count x sustained clock x MFMA FLOP/CU/clk,
  * SURVEY.md section 8(d); the reference has no counterpart). Runs `launches` back-to-back launches of a dense bf16 MFMA loop

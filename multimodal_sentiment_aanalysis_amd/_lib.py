@@ -97,6 +97,7 @@ def _declare(L):
         "mmsa_gemm_ws_bytes": (sz, [i32, i32, i32]),
         "mmsa_gemm": (ctypes.c_int, [ctypes.POINTER(GemmDesc), i32, vp]),
         "mmsa_gemm_group": (ctypes.c_int, [ctypes.POINTER(GemmDesc), i32, vp]),
+        "mmsa_gemm_group_split": (ctypes.c_int, [ctypes.POINTER(GemmDesc), i32, vp, ctypes.c_size_t, vp]),
         "mmsa_fp8_quantize_ws_bytes": (sz, []),
         "mmsa_fp8_quantize": (ctypes.c_int, [vp, i64, vp, vp, vp, vp]),
         "mmsa_gemm_fp8": (ctypes.c_int, [ctypes.POINTER(GemmDesc), vp, vp, vp]),
@@ -151,6 +152,7 @@ def _declare(L):
         "mmsa_prof_sample": (ctypes.c_int, [i32, i32]),
         "mmsa_prof_mode": (ctypes.c_int, [i32]),
         "mmsa_prof_end": (ctypes.c_int, [P(ctypes.c_double), P(ctypes.c_double), i64p]),
+        "mmsa_prof_last_bytes": (ctypes.c_double, []),
         "mmsa_bn_ws_bytes": (sz, [i32]),
         "mmsa_bn_fwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, i32, vp]),
         "mmsa_bn_bwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]),

@@ -8,6 +8,7 @@ int gemm_prof_begin(int max_records);
 int gemm_prof_sample(int stride, int phase);
 int gemm_prof_mode(int mode);
 int gemm_prof_end(double* total_ms, double* total_flop, long* launches);
+double gemm_prof_last_bytes();
 
 static GemmParams to_params(const mmsa_gemm_desc* d) {
   GemmParams p;
@@ -59,15 +60,25 @@ int mmsa_gemm(const mmsa_gemm_desc* d, int32_t impl, void* stream) {
   }
 }
 
-int mmsa_gemm_group(const mmsa_gemm_desc* d, int32_t n, void* stream) {
-  if (!d || n < 1 || n > 6) return MMSA_ERR_ARG;
-  GemmParams ps[6];
-  float* cs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+static int gemm_group_impl(const mmsa_gemm_desc* d, int32_t n, float* ws, size_t ws_bytes, void* stream) {
+  if (!d || n < 1 || n > GEMM_MAX_GROUPS) return MMSA_ERR_ARG;
+  GemmParams ps[GEMM_MAX_GROUPS];
   for (int g = 0; g < n; ++g) {
     if (!d[g].A || !d[g].B || !d[g].C) return MMSA_ERR_ARG;
+    if (d[g].gather && (d[g].geom.GH <= 0 || d[g].geom.GW <= 0 || d[g].geom.KW <= 0 || d[g].geom.cper <= 0 || d[g].geom.div <= 0))
+      return MMSA_ERR_ARG;
     ps[g] = to_params(&d[g]);
+    ps[g].split_k = 1;
+    ps[g].ws = nullptr;
   }
-  return gemm_bf16_launch_group(ps, cs, n, (hipStream_t)stream);
+  ps[0].ws = ws;
+  ps[0].ws_bytes = (long)ws_bytes;
+  return gemm_bf16_launch_group(ps, nullptr, n, (hipStream_t)stream);
+}
+int mmsa_gemm_group(const mmsa_gemm_desc* d, int32_t n, void* stream) { return gemm_group_impl(d, n, nullptr, 0, stream); }
+int mmsa_gemm_group_split(const mmsa_gemm_desc* d, int32_t n, float* ws, size_t ws_bytes, void* stream) {
+  if (!ws || ws_bytes == 0) return MMSA_ERR_ARG;
+  return gemm_group_impl(d, n, ws, ws_bytes, stream);
 }
 
 size_t mmsa_fp8_quantize_ws_bytes(void) { return fp8_quantize_ws_bytes(); }
@@ -169,5 +180,6 @@ int mmsa_prof_end(double* total_ms, double* total_flop, int64_t* launches) {
   *launches = n;
   return rc;
 }
+double mmsa_prof_last_bytes(void) { return gemm_prof_last_bytes(); }
 
 }  // extern "C"

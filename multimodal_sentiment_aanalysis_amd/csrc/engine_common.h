@@ -245,6 +245,45 @@ struct Eng {
     }
     return MMSA_OK;
   }
+  // Deferred weight gradients of several layers (each built as for gemm(): both operands k-major, fp32 output): plain problems
+  // with the same K, and convolution problems with one geometry, go out as grouped launches with ONE common K split
+  // (gemm2_launch_group: a ResNet stage's 5-11 same-size weight gradients fill the chip with 2-8 K slices instead of 16-60
+  // each); whatever does not group is launched on its own.
+  int wgrad_batch(const GemmParams* jobs, int n) const {
+    std::vector<char> done((size_t)n, 0);
+    static const bool off = [] { const char* v = getenv("MMSA_NO_WGRAD_GROUP"); return v && atoi(v) != 0; }();
+    const bool can_group = dtype == MMSA_BF16 && !force_simt() && !v1_only() && splitk_ws && !off;
+    for (int i = 0; i < n; ++i) {
+      if (done[i]) continue;
+      int idx[GEMM_MAX_GROUPS], m = 0;
+      if (can_group && jobs[i].a_kmajor && jobs[i].b_kmajor && jobs[i].out_f32) {
+        const GemmParams& a = jobs[i];
+        for (int j = i; j < n && m < GEMM_MAX_GROUPS; ++j) {
+          if (done[j]) continue;
+          const GemmParams& b = jobs[j];
+          bool same = b.a_kmajor && b.b_kmajor && b.out_f32 && a.K == b.K && a.gather == b.gather && a.accumulate == b.accumulate;
+          if (same && a.gather)
+            same = a.M == b.M && a.N == b.N && a.lda == b.lda && a.ldb == b.ldb && memcmp(&a.g, &b.g, sizeof(a.g)) == 0;
+          if (same) idx[m++] = j;
+        }
+      }
+      if (m >= 2) {
+        GemmParams ps[GEMM_MAX_GROUPS];
+        for (int k = 0; k < m; ++k) { ps[k] = jobs[idx[k]]; ps[k].split_k = 1; }
+        ps[0].ws = splitk_ws;
+        ps[0].ws_bytes = (long)splitk_bytes;
+        const int rc = gemm_bf16_launch_group(ps, nullptr, m, st);
+        if (rc != MMSA_ERR_UNSUPPORTED) {
+          if (rc) return rc;
+          for (int k = 0; k < m; ++k) done[idx[k]] = 1;
+          continue;
+        }
+      }
+      RET_IF(gemm(jobs[i]));
+      done[i] = 1;
+    }
+    return MMSA_OK;
+  }
   int bias_grad(const void* dy, long lddy, float* db, int M, int N, int accumulate) const {
     return colsum(dtype, dy, lddy, db, accumulate, col_ws, M, N, st);
   }

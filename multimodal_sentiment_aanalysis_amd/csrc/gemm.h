@@ -109,6 +109,7 @@ int gemm_bf16_launch(const GemmParams& p, hipStream_t st);
 bool gemm2_eligible(const GemmParams& p);
 int gemm2_launch(const GemmParams& p, size_t ws_bytes_avail, hipStream_t st);
 extern int g2_last_plan[3];
+#define GEMM_MAX_GROUPS 12  // problems of one grouped weight-gradient launch
 int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st);
 int gemm_bf16_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st);  // + roofline record
 int gemm_f32_launch(const GemmParams& p, hipStream_t st);

@@ -377,7 +377,21 @@ static int launch_variant(const GemmParams& p, hipStream_t st) {
 }
 
 // ---- optional live timing of the MFMA GEMM launches (bench.py roofline): HIP events on the launch stream ----------
-struct ProfRec { hipEvent_t a, b; double flop; int M, N, K, akm, bkm, gather, split, wm, nj, ksplit, epi; };
+struct ProfRec { hipEvent_t a, b; double flop, bytes; int M, N, K, akm, bkm, gather, split, wm, nj, ksplit, epi; };
+// algorithmic HBM bytes of one problem: every distinct operand read once (an implicit-GEMM gather counts each source pixel
+// once), the output written once, epilogue side operands / side outputs included
+static double alg_bytes_of(const GemmParams& p) {
+  const int taps = p.gather ? (p.g.KH * p.g.KW > 0 ? p.g.KH * p.g.KW : 1) : 1;
+  double a = (double)p.M * p.K * 2, b = (double)p.N * p.K * 2;
+  if (p.gather == 1) a = (double)p.M * (p.K / taps) * 2;
+  if (p.gather == 2) b = (double)p.K * (p.N / taps) * 2;
+  double t = a + b + (double)p.M * p.N * (p.out_f32 ? 4 : 2);
+  if (p.mul) t += (double)p.M * p.N * 2;
+  if (p.add) t += (double)p.M * p.N * 2;
+  if (p.C2) t += (double)p.M * p.N * 2;
+  if (p.out_f32 && p.accumulate) t += (double)p.M * p.N * 4;
+  return t;
+}
 static unsigned long long* g_stamp_dev = nullptr;  // [record][2]: in-kernel {min start, max end} ticks
 static size_t g_stamp_cap = 0;
 static int g_prof_mode = 0;  // 0: HIP events around each launch; 1: in-kernel clock stamps (no events)
@@ -429,6 +443,8 @@ int gemm_prof_begin(int max_records) {
   }
   return MMSA_OK;
 }
+static double g_prof_last_bytes = 0;  // algorithmic HBM bytes of the records of the latest gemm_prof_end
+double gemm_prof_last_bytes() { return g_prof_last_bytes; }
 // caller must have synchronized the stream(s); returns summed kernel time, algorithmic flop and launch count
 int gemm_prof_end(double* total_ms, double* total_flop, long* launches) {
   g_prof_on = false;
@@ -448,19 +464,21 @@ int gemm_prof_end(double* total_ms, double* total_flop, long* launches) {
     }
   }
   double ms = 0, fl = 0;
+  g_prof_last_bytes = 0;
   for (size_t i = 0; i < g_prof_used; ++i) {
     ms += dur[i];
     fl += g_prof[i].flop;
+    g_prof_last_bytes += g_prof[i].bytes;
   }
   *total_ms = ms; *total_flop = fl; *launches = (long)g_prof_used;
   if (const char* path = getenv("MMSA_PROF_DUMP")) {  // per-launch table for the profiles/ directory
     if (FILE* f = fopen(path, "w")) {
-      fprintf(f, "M,N,K,a_kmajor,b_kmajor,gather,split_k,us,tflops,tile,ksplit,epilogue\n");
+      fprintf(f, "M,N,K,a_kmajor,b_kmajor,gather,split_k,us,tflops,tile,ksplit,epilogue,alg_bytes\n");
       for (size_t i = 0; i < g_prof_used; ++i) {
         const ProfRec& r = g_prof[i];
-        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.1f,%dx%d,%d,%s\n", r.M, r.N, r.K, r.akm, r.bkm, r.gather, r.split, dur[i] * 1e3,
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.1f,%dx%d,%d,%s,%.0f\n", r.M, r.N, r.K, r.akm, r.bkm, r.gather, r.split, dur[i] * 1e3,
                 dur[i] > 0 ? r.flop / (dur[i] * 1e-3) / 1e12 : 0.0, r.wm * 64, r.nj * 16 * (r.wm ? 8 / r.wm : 0), r.ksplit,
-                r.epi == 0 ? "store" : r.epi == 1 ? "bias/act" : "side");
+                r.epi == 0 ? "store" : r.epi == 1 ? "bias/act" : "side", r.bytes);
       }
       fclose(f);
     }
@@ -476,6 +494,7 @@ int gemm_prof_open(GemmParams& p, hipStream_t st) {
   const int slot = (int)g_prof_used++;
   ProfRec& r = g_prof[slot];
   r.flop = 2.0 * p.M * p.N * (double)p.K;
+  r.bytes = alg_bytes_of(p);
   r.M = p.M; r.N = p.N; r.K = p.K; r.akm = p.a_kmajor; r.bkm = p.b_kmajor; r.gather = p.gather; r.split = p.split_k;
   r.epi = (p.mul || p.add) ? 2 : (p.bias || p.C2 || p.act != MMSA_ACT_NONE) ? 1 : 0;
   r.wm = 2; r.nj = 2; r.ksplit = p.split_k;
@@ -493,6 +512,7 @@ int gemm_bf16_launch(const GemmParams& pin, hipStream_t st) {
   if (!g_prof_on || g_prof_used >= g_prof.size() || !prof_take()) return gemm_bf16_launch_inner(pin, st);
   ProfRec& r = g_prof[g_prof_used];
   r.flop = 2.0 * pin.M * pin.N * (double)pin.K;
+  r.bytes = alg_bytes_of(pin);
   r.M = pin.M; r.N = pin.N; r.K = pin.K; r.akm = pin.a_kmajor; r.bkm = pin.b_kmajor; r.gather = pin.gather; r.split = pin.split_k;
   r.epi = (pin.mul || pin.add) ? 2 : (pin.bias || pin.C2 || pin.act != MMSA_ACT_NONE) ? 1 : 0;
   g2_last_plan[0] = g2_last_plan[1] = g2_last_plan[2] = 0;
@@ -520,11 +540,16 @@ int gemm_bf16_launch_group(const GemmParams* probs, float* const* colsum, int n,
   if (!g_prof_on || g_prof_used >= g_prof.size() || !prof_take()) return gemm2_launch_group(probs, colsum, n, st);
   ProfRec& r = g_prof[g_prof_used];
   r.flop = 0;
-  for (int g = 0; g < n; ++g) r.flop += 2.0 * probs[g].M * probs[g].N * (double)probs[g].K;
-  r.M = -n; r.N = 0; r.K = probs[0].K; r.akm = 1; r.bkm = 1; r.gather = 0; r.split = 1; r.epi = 0;
+  r.bytes = 0;
+  for (int g = 0; g < n; ++g) {
+    r.flop += 2.0 * probs[g].M * probs[g].N * (double)probs[g].K;
+    r.bytes += alg_bytes_of(probs[g]);
+  }
+  r.M = -n; r.N = 0; r.K = probs[0].K; r.akm = 1; r.bkm = 1; r.gather = probs[0].gather; r.split = 1; r.epi = 0;
+  for (int g = 0; g < n; ++g) r.N += probs[g].M + probs[g].N;  // (grouped rows: N = the summed operand widths)
   if (g_prof_mode == 1) {
-    GemmParams ps[8];
-    if (n > 8) return MMSA_ERR_UNSUPPORTED;
+    GemmParams ps[GEMM_MAX_GROUPS];
+    if (n > GEMM_MAX_GROUPS) return MMSA_ERR_UNSUPPORTED;
     for (int g = 0; g < n; ++g) ps[g] = probs[g];
     ps[0].stamp = g_stamp_dev + 2 * g_prof_used;
     const int rc = gemm2_launch_group(ps, colsum, n, st);

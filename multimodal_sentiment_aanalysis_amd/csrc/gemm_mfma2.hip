@@ -37,7 +37,7 @@
 #define G2_GROUP_COLSUM 0
 #endif
 
-#define G2_MAX_GROUPS 6
+#define G2_MAX_GROUPS GEMM_MAX_GROUPS
 struct G2Sched {
   int ntm, ntn, ntiles;  // tile grid
   int split_k, per;      // K splits; K steps per split
@@ -48,8 +48,11 @@ struct G2Sched {
   unsigned c_bytes;      // byte extent of the output view (C, or the split-K slabs)
   int rb, cb;            // 2-D blocking of the tile order (rb x cb tiles = one XCD's round), 0 = row-major
   FastDiv fd_cb, fd_sbc;  // divisors: cb, super-blocks per row of super-blocks
-  // grouped launch (weight gradients of one BERT layer): up to 4 independent TN problems with the same K share one
-  // launch, so their 18-72 tiles each add up to ~216 work items without any K split (no slabs, no reducer)
+  // grouped launch (weight gradients of one BERT layer / of one ResNet stage): independent TN problems with the same K share
+  // one launch. BERT: 4 + 2 problems of 18-72 tiles add up to ~216 work items without any K split (no slabs, no reducer).
+  // ResNet: the 5-11 same-shape 1x1 weight gradients of a stage (or its 2-5 same-geometry 3x3 ones, GATHER 2) with ONE common
+  // K split: launched one by one each needed 16-60 slices of 4-13 K steps to fill the chip; together they need 2-8 slices of
+  // 25-100 steps (C of a group then points at its slab region, and one grouped reducer launch follows).
   int ngroups;
   struct Group {
     const void* A; const void* B; void* C; float* colsum;  // colsum: optional sum_k A[k][m] (the bias gradient)
@@ -164,21 +167,28 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   stamp_begin(s.stamp);
 
   // ---- item decode (all scalar)
-  constexpr bool GROUPS = A_KM && B_KM && GATHER == 0;  // only the TN instantiations carry the group code
-  constexpr bool GCOLSUM = GROUPS && G2_GROUP_COLSUM;   // ... and (optionally) the fused column sums
+  constexpr bool GROUPS = A_KM && B_KM && (GATHER == 0 || GATHER == 2);  // only the TN instantiations carry the group code
+  constexpr bool GCOLSUM = GROUPS && GATHER == 0 && G2_GROUP_COLSUM;     // ... and (optionally) the fused column sums
   struct Item { int m0, n0, kb, nk, sp, grp, tn; };
   auto decode = [&](int item) __attribute__((always_inline)) -> Item {
     Item it;
     it.grp = 0;
     if constexpr (GROUPS) {
       if (s.ngroups > 0) {
+        int sp = 0, gt = item;  // K slice, tile index over all problems
+        if (s.split_k > 1) {
+          sp = (int)fd_div((uint32_t)item, s.fd_ntiles);
+          gt = item - sp * s.ntiles;
+        }
         int g = 0;
 #pragma unroll
         for (int q = 1; q < G2_MAX_GROUPS; ++q)
-          if (q < s.ngroups && item >= s.grp[q].tile_begin) g = q;
-        const int tile = item - s.grp[g].tile_begin;
+          if (q < s.ngroups && gt >= s.grp[q].tile_begin) g = q;
+        const int tile = gt - s.grp[g].tile_begin;
         const int tm = tile / s.grp[g].ntn, tn = tile - tm * s.grp[g].ntn;
-        it.m0 = tm * BM; it.n0 = tn * BN; it.sp = 0; it.kb = 0; it.nk = s.nsteps; it.grp = g; it.tn = tn;
+        it.m0 = tm * BM; it.n0 = tn * BN; it.sp = sp; it.grp = g; it.tn = tn;
+        it.kb = sp * s.per;
+        it.nk = min(s.per, s.nsteps - it.kb);
         return it;
       }
     }
@@ -1499,37 +1509,108 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   return MMSA_OK;
 }
 
-// Grouped launch: n (2..6) independent weight-gradient problems C_g[M_g, N_g] = A_g^T B_g with the same K, both operands
-// k-major, fp32 output (overwrite), no K split: one persistent launch walks the tiles of all problems. colsum[g]
-// (optional) receives sum_k A_g[k][m] = the bias gradient of that Linear. Returns MMSA_ERR_UNSUPPORTED when the
-// problems do not fit (the caller then launches them one by one).
+// Second pass of a grouped launch with a K split: one launch sums the slabs of every problem (slab order = fixed summation
+// order -> bitwise reproducible) into its fp32 output (overwrite or +=).
+struct G2GroupReduce {
+  int n, split, accumulate;
+  long total4;
+  unsigned long long* stamp;
+  struct { const float* slab; float* C; long mn, ldc, begin4; int N; } g[G2_MAX_GROUPS];
+};
+__global__ __launch_bounds__(256) void gemm2_group_reduce_kernel(G2GroupReduce a) {
+  const bool stamped = (blockIdx.x & 15) == 0 || blockIdx.x == gridDim.x - 1;
+  if (stamped) stamp_begin(a.stamp);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long)gridDim.x * 256) {
+    int g = 0;
+#pragma unroll
+    for (int q = 1; q < G2_MAX_GROUPS; ++q)
+      if (q < a.n && i >= a.g[q].begin4) g = q;
+    const long e = (i - a.g[g].begin4) * 4;
+    const float* src = a.g[g].slab + e;
+    f32x4 v = *(const f32x4*)src;
+    for (int sp = 1; sp < a.split; ++sp) v += *(const f32x4*)(src + (long)sp * a.g[g].mn);
+    const long m = e / a.g[g].N, nn = e - m * a.g[g].N;
+    float* dst = a.g[g].C + m * a.g[g].ldc + nn;
+    if (a.accumulate) v += *(const f32x4*)dst;
+    *(f32x4*)dst = v;
+  }
+  if (stamped) stamp_end(a.stamp);
+}
+
+// Grouped launch: n (2..G2_MAX_GROUPS) independent weight-gradient problems C_g[M_g, N_g] = A_g^T B_g with the same K, both
+// operands k-major, fp32 output: one persistent launch walks the tiles of all problems. Either plain TN problems (any M_g, N_g)
+// or implicit-GEMM weight gradients of convolutions with ONE geometry (gather 2: same M, N and ConvGeom; only the pointers
+// differ). Without a workspace (probs[0].ws == null): no K split, overwrite only — the BERT layer group; colsum[g] (optional)
+// receives sum_k A_g[k][m] = the bias gradient of that Linear. With probs[0].ws / ws_bytes: a K split common to the group is
+// planned, the tiles store slabs and gemm2_group_reduce_kernel finishes (overwrite or accumulate). Returns
+// MMSA_ERR_UNSUPPORTED when the problems do not fit (the caller then launches them one by one).
 int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st) {
   if (n < 1 || n > G2_MAX_GROUPS) return MMSA_ERR_UNSUPPORTED;
-  const int K = probs[0].K;
+  const int K = probs[0].K, gather = probs[0].gather;
+  float* ws = probs[0].ws;
+  const size_t ws_bytes = ws ? (size_t)probs[0].ws_bytes : 0;
+  const int accumulate = probs[0].accumulate;
+  if (gather != 0 && gather != 2) return MMSA_ERR_UNSUPPORTED;
+  if (accumulate && !ws) return MMSA_ERR_UNSUPPORTED;
+  long sum_mn = 0;
   for (int g = 0; g < n; ++g) {
     const GemmParams& q = probs[g];
-    if (!(q.a_kmajor && q.b_kmajor) || q.gather || q.K != K || !q.out_f32 || q.accumulate || q.bias || q.C2 || q.mul ||
-        q.add || q.act != MMSA_ACT_NONE || !gemm2_eligible(q))
+    if (!(q.a_kmajor && q.b_kmajor) || q.gather != gather || q.K != K || !q.out_f32 || q.accumulate != accumulate || q.bias ||
+        q.C2 || q.mul || q.add || q.act != MMSA_ACT_NONE || q.c_gw > 0 || q.colstat || !gemm2_eligible(q))
       return MMSA_ERR_UNSUPPORTED;
+    if (gather == 2 && (q.M != probs[0].M || q.N != probs[0].N || q.lda != probs[0].lda || q.ldb != probs[0].ldb ||
+                        memcmp(&q.g, &probs[0].g, sizeof(q.g)) != 0))
+      return MMSA_ERR_UNSUPPORTED;
+    sum_mn += (long)q.M * q.N;
   }
   const int cus = g2_num_cus();
-  // one tile shape for the whole group: the widest 256-row tile whose total tile count fills the chip best
+  const int nsteps = K / G2_BK;
+  // one tile shape and one K split for the whole group (cost model of g2_plan_search; without a workspace: the widest
+  // 256-row tile whose total tile count fills the chip best, as before)
   G2Plan plan{4, 4, 1};
   {
+    const G2Model& mdl = g2_model();
     double best = 1e300;
-    for (int nj = 4; nj >= 2; --nj) {
-      long tiles = 0;
-      for (int g = 0; g < n; ++g) tiles += (long)cdiv(probs[g].M, 256) * cdiv(probs[g].N, nj * 32);
-      const long rounds = (tiles + cus - 1) / cus;
-      const double cost = rounds * ((K / G2_BK) * (1.0 + 0.06 * nj) + 0.3 + 0.2 * nj);
-      if (cost < best - 1e-9) { best = cost; plan.nj = nj; }
+    static const int cfgs[5][2] = {{4, 4}, {4, 3}, {4, 2}, {2, 2}, {2, 1}};
+    int smax = 1;
+    if (ws) {
+      smax = nsteps / 2;
+      const long cap = (long)(ws_bytes / ((size_t)sum_mn * sizeof(float)));
+      if (cap < smax) smax = (int)cap;
+      if (smax > 128) smax = 128;
+      if (smax < 1) smax = 1;
+      if (accumulate && smax < 1) return MMSA_ERR_UNSUPPORTED;
     }
+    for (int ci = 0; ci < (ws ? 5 : 3); ++ci) {
+      const G2Plan shape{cfgs[ci][0], cfgs[ci][1], 1};
+      const int bm = g2_bm(shape), bn = g2_bn(shape), w32 = bn / 32;
+      long tiles = 0;
+      for (int g = 0; g < n; ++g) tiles += (long)cdiv(probs[g].M, bm) * cdiv(probs[g].N, bn);
+      const double t_step = shape.wm == 4 ? mdl.a4 + mdl.b4 * w32 : mdl.a2 + mdl.b2 * w32;
+      const double t_item = shape.wm == 4 ? 0.3 + 0.2 * w32 : 0.3 + 0.1 * w32;
+      for (int sp = (accumulate ? 2 : 1); sp <= (smax > 1 ? smax : (accumulate ? 2 : 1)); ++sp) {
+        const int per = cdiv(nsteps, sp);
+        const int split = cdiv(nsteps, per);
+        if (split != sp) continue;  // (no empty slices)
+        const long items = tiles * split;
+        const long rounds = (items + cus - 1) / cus;
+        double cost = (double)rounds * (per * t_step + t_item);
+        if (split > 1) cost += mdl.c_split + mdl.d_split * split * (double)sum_mn * 4.0 / 4e6;
+        if (cost < best - 1e-9) { best = cost; plan = G2Plan{shape.wm, shape.nj, split}; }
+      }
+    }
+    if (best >= 1e300) return MMSA_ERR_UNSUPPORTED;
+    if (plan.split > 1 && (size_t)plan.split * sum_mn * sizeof(float) > ws_bytes) return MMSA_ERR_UNSUPPORTED;
+    if (plan.split > 1 && (long)plan.split * sum_mn * 4 >= 0x7FFFFFF0L) return MMSA_ERR_UNSUPPORTED;
   }
   G2Sched s;
   memset(&s, 0, sizeof(s));
-  const int bn = g2_bn(plan);
+  const int bm = g2_bm(plan), bn = g2_bn(plan);
   s.ngroups = n;
   int tiles = 0;
+  long slab_off = 0;
+  G2GroupReduce red;
+  memset(&red, 0, sizeof(red));
   for (int g = 0; g < n; ++g) {
     const GemmParams& q = probs[g];
     G2Sched::Group& gr = s.grp[g];
@@ -1537,15 +1618,26 @@ int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hip
     gr.M = q.M; gr.N = q.N; gr.lda = q.lda; gr.ldb = q.ldb; gr.ldc = q.ldc;
     gr.tile_begin = tiles;
     gr.ntn = cdiv(q.N, bn);
-    tiles += cdiv(q.M, 256) * gr.ntn;
+    tiles += cdiv(q.M, bm) * gr.ntn;
     long ea, eb;
     g2_extents(q, &ea, &eb);
     gr.a_bytes = (unsigned)ea; gr.b_bytes = (unsigned)eb;
     gr.c_bytes = (unsigned)(((long)(q.M - 1) * q.ldc + q.N) * 4);
+    if (plan.split > 1) {  // the tiles of this problem store into its own slab region
+      const long mn = (long)q.M * q.N;
+      gr.C = ws + slab_off;
+      gr.c_bytes = (unsigned)((long)plan.split * mn * 4);
+      red.g[g].slab = ws + slab_off; red.g[g].C = (float*)q.C; red.g[g].mn = mn; red.g[g].ldc = q.ldc;
+      red.g[g].begin4 = red.total4; red.g[g].N = q.N;
+      red.total4 += mn / 4;
+      slab_off += (long)plan.split * mn;
+    }
   }
   s.ntm = 1; s.ntn = 1; s.ntiles = tiles;
-  s.nsteps = K / G2_BK;
-  s.split_k = 1; s.per = s.nsteps; s.items = tiles;
+  s.nsteps = nsteps;
+  s.split_k = plan.split;
+  s.per = cdiv(nsteps, plan.split);
+  s.items = tiles * plan.split;
   s.fd_ntiles = make_fastdiv((uint32_t)tiles);
   s.fd_ntn = make_fastdiv(1);
   s.fd_cb = make_fastdiv(1); s.fd_sbc = make_fastdiv(1);
@@ -1554,19 +1646,36 @@ int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hip
   s.c_bytes = s.grp[0].c_bytes;
   if (const char* d = getenv("MMSA_G2_DBG")) s.dbg = atoi(d);
   GemmParams p = probs[0];
-  p.split_k = 1;
+  p.split_k = plan.split;
+  p.accumulate = 0;
+  p.ws = ws;
   p.a_bytes = s.grp[0].a_bytes; p.b_bytes = s.grp[0].b_bytes;
-  const int grid = tiles < cus ? tiles : cus;
-  g2_last_plan[0] = plan.wm; g2_last_plan[1] = plan.nj; g2_last_plan[2] = 1;
+  const int grid = s.items < cus ? s.items : cus;
+  g2_last_plan[0] = plan.wm; g2_last_plan[1] = plan.nj; g2_last_plan[2] = plan.split;
+  int rc;
 #ifdef G2_ONLY_BIG
 #ifdef G2_ONLY_GROUP  // (-DG2_ONLY_BIG -DG2_ONLY_GROUP: the grouped 256 x 128 TN kernel alone)
-  return g2_launch_t<4, 4, true, true, 0>(p, s, grid, st);
+  rc = g2_launch_t<4, 4, true, true, 0>(p, s, grid, st);
 #else
   return MMSA_ERR_UNSUPPORTED;
 #endif
 #else
-  if (plan.nj == 4) return g2_launch_t<4, 4, true, true, 0>(p, s, grid, st);
-  if (plan.nj == 3) return g2_launch_t<4, 3, true, true, 0>(p, s, grid, st);
-  return g2_launch_t<4, 2, true, true, 0>(p, s, grid, st);
+  if (plan.wm == 4) {
+    if (plan.nj == 4) rc = g2_launch_nj<4, 4>(p, s, grid, st);
+    else if (plan.nj == 3) rc = g2_launch_nj<4, 3>(p, s, grid, st);
+    else rc = g2_launch_nj<4, 2>(p, s, grid, st);
+  } else {
+    if (plan.nj == 2) rc = g2_launch_nj<2, 2>(p, s, grid, st);
+    else rc = g2_launch_nj<2, 1>(p, s, grid, st);
+  }
 #endif
+  if (rc) return rc;
+  if (plan.split > 1) {
+    red.n = n; red.split = plan.split; red.accumulate = accumulate; red.stamp = probs[0].stamp;
+    long blocks = (red.total4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm2_group_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, red);
+    MMSA_CHECK_LAUNCH();
+  }
+  return MMSA_OK;
 }

@@ -95,6 +95,8 @@ struct ResWs {
   void *pooled, *dfeat_t, *dpooled;
   void *g0, *g1, *g2, *g3;  // gradient ping-pong buffers (largest activation size)
   void* foldw;  // inference: one convolution's weights with its BatchNorm scale folded in (largest weight)
+  void* dzarena;  // backward: the pre-BatchNorm gradients dz of one stage's convolutions, kept until the stage's weight gradients
+  size_t dzarena_bytes;  // go out as grouped launches (Eng::wgrad_batch)
   float *stem_dw, *splitk, *colws, *bnws;
   long bnws_floats;  // capacity of the partial-sum part of bnws (conv-epilogue statistics: GemmParams::colstat_cap)
   size_t splitk_bytes;
@@ -152,6 +154,20 @@ static ResWs res_ws(const mmsa_resnet_cfg& c, const ResLayout& L, void* base) {
   w.g1 = b.take(maxact * es);
   w.g2 = b.take(maxact * es);
   w.g3 = b.take(maxact * es);
+  {
+    // largest per-stage sum of convolution outputs (a stage = the blocks down to and including one with a downsample branch)
+    size_t run = 0, best = 0;
+    for (int i = (int)L.blocks.size() - 1; i >= 0; --i) {
+      const BlockDef& bd = L.blocks[i];
+      const ConvDef* cs[4] = {&bd.c1, &bd.c2, &bd.c3, bd.has_ds ? &bd.ds : nullptr};
+      for (const ConvDef* cd : cs)
+        if (cd) run += align_up((size_t)B * cd->Hout * cd->Wout * cd->Cout * es, 256);
+      if (run > best) best = run;
+      if (bd.has_ds) run = 0;
+    }
+    w.dzarena_bytes = best;
+    w.dzarena = b.take(best);
+  }
   w.stem_dw = (float*)b.take((size_t)64 * L.Kstem_pad * 4);
   w.foldw = b.take(maxw * es);
   // split-K slabs for the weight gradients: up to 64 slabs of the small early-stage weights, fewer of the large ones
@@ -298,7 +314,7 @@ static int conv_dgrad(const ResCtx& r, const ConvDef& c, const void* dz, void* d
   return r.e.gemm(p);
 }
 // dW[Cout][k*k*Cin] (+)= dz^T gathered(x)
-static int conv_wgrad(const ResCtx& r, const ConvDef& c, const void* dz, const void* x, float* dW, int accumulate) {
+static GemmParams conv_wgrad_params(const ResCtx& r, const ConvDef& c, const void* dz, const void* x, float* dW, int accumulate) {
   const int B = r.c.batch, Kred = B * c.Hout * c.Wout, N = c.k * c.k * c.Cin;
   GemmParams p = Eng::blank();
   p.A = dz; p.lda = c.Cout; p.a_kmajor = 1; p.B = x; p.ldb = c.Cin; p.b_kmajor = 1; p.C = dW; p.ldc = N;
@@ -310,7 +326,10 @@ static int conv_wgrad(const ResCtx& r, const ConvDef& c, const void* dz, const v
   }
   p.split_k = r.e.pick_split(c.Cout, N, Kred);
   p.ws = r.e.splitk_ws;
-  return r.e.gemm(p);
+  return p;
+}
+static int conv_wgrad(const ResCtx& r, const ConvDef& c, const void* dz, const void* x, float* dW, int accumulate) {
+  return r.e.gemm(conv_wgrad_params(r, c, dz, x, dW, accumulate));
 }
 
 // the ReLU sign bits of a block output (MMSA_NO_BN_MASK=1: the backward reads the saved output instead; A/B hook)
@@ -537,6 +556,36 @@ int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* 
   RET_IF(avgpool_bwd(c.dtype, ws.dpooled, dOut, B, L.Hf * L.Wf, L.feat_c, st));
   long chunk_end = L.wproj;
   bool chunk_live = false;
+  // Weight gradients are deferred to the end of their stage and launched in groups (Eng::wgrad_batch): every dz then lives in its
+  // own slot of the arena instead of the ping-pong buffer. MMSA_NO_WGRAD_DEFER=1 (A/B hook) and the non-bf16 modes launch them in place.
+  const bool defer = c.dtype == MMSA_BF16 && !Eng::force_simt() && !Eng::v1_only() &&
+                     !(getenv("MMSA_NO_WGRAD_DEFER") && atoi(getenv("MMSA_NO_WGRAD_DEFER")) != 0);
+  std::vector<GemmParams> pend;
+  size_t arena_off = 0;
+  auto flush = [&]() -> int {
+    const int rc = pend.empty() ? MMSA_OK : r.e.wgrad_batch(pend.data(), (int)pend.size());
+    pend.clear();
+    arena_off = 0;
+    return rc;
+  };
+  // where the dz of convolution cd goes: its arena slot (deferred) or the ping-pong buffer `fallback`
+  auto dz_slot = [&](const ConvDef& cd, void* fallback, bool wg, void** out) -> int {
+    *out = fallback;
+    if (!defer || !wg) return MMSA_OK;
+    const size_t need = align_up((size_t)B * cd.Hout * cd.Wout * cd.Cout * r.es, 256);
+    if (need > ws.dzarena_bytes) return MMSA_OK;
+    if (arena_off + need > ws.dzarena_bytes) RET_IF(flush());
+    *out = (char*)ws.dzarena + arena_off;
+    arena_off += need;
+    return MMSA_OK;
+  };
+  auto wgrad = [&](const ConvDef& cd, const void* dz, const void* x) -> int {
+    if (defer && dz >= ws.dzarena && dz < (const void*)((const char*)ws.dzarena + ws.dzarena_bytes)) {
+      pend.push_back(conv_wgrad_params(r, cd, dz, x, r.G(cd.w), acc));
+      return MMSA_OK;
+    }
+    return conv_wgrad(r, cd, dz, x, r.G(cd.w), acc);
+  };
   for (int i = (int)L.blocks.size() - 1; i >= 0 && i >= lowest; --i) {
     const BlockDef& bd = L.blocks[i];
     const bool wg = !blk_frozen[i], last_needed = (i == lowest);
@@ -544,36 +593,47 @@ int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* 
     BlockWs& bw = ws.blocks[i];
     const void* xin = i == 0 ? ws.pool : ws.blocks[i - 1].c3.y;
     // out = relu(bn3(z3) + idn): dz3 -> t1, masked gradient of the identity branch -> t2
-    RET_IF(bn_bwd(r, bd.c3, bw.c3, dOut, bw.c3.y, t1, t2, MMSA_ACT_RELU, ws.bnws, wg));
-    if (wg) RET_IF(conv_wgrad(r, bd.c3, t1, bw.c2.y, r.G(bd.c3.w), acc));
-    RET_IF(conv_dgrad(r, bd.c3, t1, t3, nullptr));                                   // dy2 -> t3
-    RET_IF(bn_bwd(r, bd.c2, bw.c2, t3, nullptr, t1, nullptr, MMSA_ACT_RELU, ws.bnws, wg));  // dz2 -> t1
-    if (wg) RET_IF(conv_wgrad(r, bd.c2, t1, bw.c1.y, r.G(bd.c2.w), acc));
-    RET_IF(conv_dgrad(r, bd.c2, t1, t3, nullptr));                                   // dy1 -> t3
-    RET_IF(bn_bwd(r, bd.c1, bw.c1, t3, nullptr, t1, nullptr, MMSA_ACT_RELU, ws.bnws, wg));  // dz1 -> t1
+    void *dz3, *dz2, *dz1, *dzd;  // (t1 / t3 unless the weight gradient is deferred: then a slot of the arena)
+    RET_IF(dz_slot(bd.c3, t1, wg, &dz3));
+    RET_IF(bn_bwd(r, bd.c3, bw.c3, dOut, bw.c3.y, dz3, t2, MMSA_ACT_RELU, ws.bnws, wg));
+    if (wg) RET_IF(wgrad(bd.c3, dz3, bw.c2.y));
+    RET_IF(conv_dgrad(r, bd.c3, dz3, t3, nullptr));                                   // dy2 -> t3
+    RET_IF(dz_slot(bd.c2, t1, wg, &dz2));
+    RET_IF(bn_bwd(r, bd.c2, bw.c2, t3, nullptr, dz2, nullptr, MMSA_ACT_RELU, ws.bnws, wg));  // dz2
+    if (wg) RET_IF(wgrad(bd.c2, dz2, bw.c1.y));
+    RET_IF(conv_dgrad(r, bd.c2, dz2, t3, nullptr));                                   // dy1 -> t3
+    RET_IF(dz_slot(bd.c1, t1, wg, &dz1));
+    RET_IF(bn_bwd(r, bd.c1, bw.c1, t3, nullptr, dz1, nullptr, MMSA_ACT_RELU, ws.bnws, wg));  // dz1
     if (const char* dbg = getenv("MMSA_RESNET_BWD_STOP_BLOCK")) {  // diagnostic: leave t3 = dy1, t1 = dz1 of block i intact
-      if (atoi(dbg) == i) return MMSA_OK;
+      if (atoi(dbg) == i) {
+        if (dz1 != t1 && hipMemcpyAsync(t1, dz1, (size_t)B * bd.c1.Hout * bd.c1.Wout * bd.c1.Cout * r.es, hipMemcpyDeviceToDevice, st) != hipSuccess)
+          return MMSA_ERR_LAUNCH;
+        return flush();
+      }
     }
-    if (wg) RET_IF(conv_wgrad(r, bd.c1, t1, xin, r.G(bd.c1.w), acc));
+    if (wg) RET_IF(wgrad(bd.c1, dz1, xin));
     const void* skip = t2;  // identity block: the skip gradient is added to conv1's data gradient
     if (bd.has_ds) {
-      RET_IF(bn_bwd(r, bd.ds, bw.ds, t2, nullptr, t3, nullptr, MMSA_ACT_NONE, ws.bnws, wg));  // dzd -> t3
-      if (wg) RET_IF(conv_wgrad(r, bd.ds, t3, xin, r.G(bd.ds.w), acc));
+      RET_IF(dz_slot(bd.ds, t3, wg, &dzd));
+      RET_IF(bn_bwd(r, bd.ds, bw.ds, t2, nullptr, dzd, nullptr, MMSA_ACT_NONE, ws.bnws, wg));  // dzd
+      if (wg) RET_IF(wgrad(bd.ds, dzd, xin));
       if (!last_needed) {
-        RET_IF(conv_dgrad(r, bd.ds, t3, dOut, nullptr));  // dOut is free: holds the projected-skip data gradient
+        RET_IF(conv_dgrad(r, bd.ds, dzd, dOut, nullptr));  // dOut is free: holds the projected-skip data gradient
         skip = dOut;
-        RET_IF(conv_dgrad(r, bd.c1, t1, t2, skip));       // dx -> t2
+        RET_IF(conv_dgrad(r, bd.c1, dz1, t2, skip));       // dx -> t2
         void* t = dOut; dOut = t2; t2 = t;
       }
     } else if (!last_needed) {
-      RET_IF(conv_dgrad(r, bd.c1, t1, dOut, skip));     // dx -> dOut (its old content was consumed by bn3's backward)
+      RET_IF(conv_dgrad(r, bd.c1, dz1, dOut, skip));     // dx -> dOut (its old content was consumed by bn3's backward)
     }
     if (bd.has_ds || last_needed) {  // first bottleneck of a stage (or the last one needed): the stage's gradients are enqueued
+      RET_IF(flush());
       if (cb && chunk_live) cb(user, bd.c1.w, chunk_end - bd.c1.w);
       chunk_end = bd.c1.w;
       chunk_live = false;
     }
   }
+  RET_IF(flush());
   if (lowest >= 0) return MMSA_OK;  // the stem is frozen
   // max-pool, stem BN + ReLU, stem conv (weight gradient only: the image needs none)
   const ConvDef& s = L.stem;

@@ -96,18 +96,26 @@ def gemm_fp8(Aq, sa, Bq, sb, C, bias=None, act=ACT_NONE, add=None, C2=None):
     return L.mmsa_gemm_fp8(ctypes.byref(d), ptr(sa), ptr(sb), stream_ptr())
 
 
-def gemm_group(jobs):
+def gemm_group(jobs, ws_bytes=0, geom=None, accumulate=0):
     """jobs: list of (A[K,M] k-major, B[K,N] k-major, C[M,N] fp32) -> one grouped weight-gradient launch (mmsa_gemm_group).
+    ws_bytes > 0: with a K split planned inside a workspace of that size (mmsa_gemm_group_split); geom: every job is the weight
+    gradient of a convolution with this geometry (gather 2: B is the [pixels][Cin] activation, C is [Cout][taps * Cin]).
     Returns the status code (3 = the library declined to group them)."""
     L = _lib.load()
     arr = (GemmDesc * len(jobs))()
     for d, (A, B, C) in zip(arr, jobs):
         Kd, M = A.shape
-        N = B.shape[1]
+        N = C.shape[1]
         d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
         d.M, d.N, d.K = M, N, Kd
-        d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), C.stride(0)
-        d.a_kmajor, d.b_kmajor, d.out_f32, d.split_k = 1, 1, 1, 1
+        d.lda, d.ldb, d.ldc = A.stride(0), B.stride(-2), C.stride(0)
+        d.a_kmajor, d.b_kmajor, d.out_f32, d.split_k, d.accumulate = 1, 1, 1, 1, accumulate
+        if geom is not None:
+            d.gather = 2
+            d.geom = geom
+    if ws_bytes > 0:
+        ws = workspace(ws_bytes, jobs[0][0].device, "group_splitk")
+        return L.mmsa_gemm_group_split(arr, len(jobs), ws.data_ptr(), ws_bytes, stream_ptr())
     return L.mmsa_gemm_group(arr, len(jobs), stream_ptr())
 
 

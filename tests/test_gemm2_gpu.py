@@ -195,6 +195,54 @@ def test_g2_group(dev):
             close(C.double(), ref, f"group K={Kd} {tuple(C.shape)}", tol=2e-5)
 
 
+def test_g2_group_split_plain(dev):
+    """The 1x1 weight gradients of a ResNet-50 stage as ONE launch with a common K split (mmsa_gemm_group_split): stage 3 at
+    B = 64 (six 1024x256 and five 256x1024 outputs, K = 12544 pixels), a ragged small group, and the accumulating form."""
+    for Kd, shapes, acc in [(12544, [(1024, 256)] * 6 + [(256, 1024)] * 5, 0), (640, [(136, 264), (520, 72), (64, 64)], 0),
+                            (3136, [(2048, 512), (512, 2048), (2048, 512)], 1)]:
+        jobs, refs = [], []
+        for i, (M, N) in enumerate(shapes):
+            A = rnd((Kd, M), dev, 10 + i, 0.5)
+            B = rnd((Kd, N), dev, 40 + i, 0.5)
+            if acc:
+                C = rnd((M, N), dev, 70 + i, 3.0).float()
+                refs.append(C.double() + A.double().T @ B.double())
+            else:
+                C = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+                refs.append(A.double().T @ B.double())
+            jobs.append((A, B, C))
+        rc = K.gemm_group(jobs, ws_bytes=96 << 20, accumulate=acc)
+        assert rc == 0, rc
+        for (A, B, C), ref in zip(jobs, refs):
+            close(C.double(), ref, f"group split K={Kd} {tuple(C.shape)}", tol=2e-5)
+        if not acc:  # bitwise reproducible: the slabs are summed in slab order
+            again = [(A, B, torch.empty_like(C)) for A, B, C in jobs]
+            assert K.gemm_group(again, ws_bytes=96 << 20) == 0
+            for (_, _, C0), (_, _, C1) in zip(jobs, again):
+                assert torch.equal(C0, C1)
+
+
+@pytest.mark.parametrize("cfg", [(16, 14, 14, 64, 64, 3, 1, 1, 5), (4, 28, 28, 128, 128, 3, 1, 1, 3), (64, 7, 7, 64, 128, 3, 1, 1, 2)])
+def test_g2_group_split_conv(dev, cfg):
+    """Same-geometry 3x3 weight gradients (implicit GEMM over the activation, gather 2) as one grouped launch with a K split."""
+    B, H, W, Cin, Cout, k, s, p, n = cfg
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    Kd = k * k * Cin
+    g = K.conv_geom(H, W, OH, OW, k, k, s, 1, -p, 1, Cin, Cin)
+    jobs, refs = [], []
+    for i in range(n):
+        x = rnd((B, H, W, Cin), dev, 100 + i)
+        dy = rnd((B, OH, OW, Cout), dev, 200 + i)
+        wr = torch.zeros((Cout, Cin, k, k), device=dev, requires_grad=True)
+        F.conv2d(x.float().permute(0, 3, 1, 2), wr, stride=s, padding=p).backward(dy.float().permute(0, 3, 1, 2))
+        refs.append(wr.grad.permute(0, 2, 3, 1).reshape(Cout, Kd))
+        jobs.append((dy.view(B * OH * OW, Cout), x, torch.full((Cout, Kd), float("nan"), dtype=torch.float32, device=dev)))
+    rc = K.gemm_group(jobs, ws_bytes=64 << 20, geom=g)
+    assert rc == 0, rc
+    for (_, _, C), ref in zip(jobs, refs):
+        close(C, ref, f"grouped conv wgrad {cfg}", tol=2e-3)
+
+
 def test_g2_group_with_bias_problems(dev):
     """A BERT-base layer's group as the engine launches it: four weight gradients plus two bias gradients expressed as
     dY^T x ones[K][8] (every column of the [N][8] result is the column sum of dY), six problems in one launch."""

@@ -13,7 +13,13 @@ def main():
     I = int(sys.argv[4]) if len(sys.argv) > 4 else 3072
     rows = list(csv.DictReader(open(path)))
     total, flop = 0.0, 0.0
-    for r in rows:
+    if rows and rows[0].get("alg_bytes"):  # newer dumps carry the library's own count per launch (side operands included)
+        total = sum(float(r["alg_bytes"]) for r in rows)
+        flop = sum(float(r["tflops"]) * float(r["us"]) * 1e6 for r in rows)
+        rows_iter = []
+    else:
+        rows_iter = rows
+    for r in rows_iter:
         M, N, K = int(r["M"]), int(r["N"]), int(r["K"])
         g, akm, bkm = int(r["gather"]), int(r["a_kmajor"]), int(r["b_kmajor"])
         f = float(r["tflops"]) * float(r["us"]) * 1e6

@@ -12,7 +12,7 @@ batch = bench.synth_batch(64, 128, 30522, dev, 1234)
 for _ in range(3): step.step(*batch)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step.step(*batch)
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=60))
@@ -20,3 +20,14 @@ rows = [(e.key, e.count, e.self_device_time_total) for e in prof.key_averages() 
 print("\naten-level ops in one step (name, calls, self device us):")
 for k, c, t in sorted(rows, key=lambda r: -r[1]):
     print(f"  {k[:70]:70s} {c:4d} {t:9.1f}")
+
+print("\naten ops with their Python call sites (calls, op <- innermost repo frames):")
+sites = {}
+for e in prof.events():
+    if not e.name.startswith("aten::") or e.cpu_parent is not None and e.cpu_parent.name.startswith("aten::"):
+        continue
+    st = [f for f in (e.stack or []) if "multimodal_sentiment" in f or "bench.py" in f][:2]
+    k = (e.name, " <- ".join(f.split("/")[-1] for f in st))
+    sites[k] = sites.get(k, 0) + 1
+for (n, st), c in sorted(sites.items(), key=lambda r: -r[1]):
+    print(f"  {c:4d} {n:28s} {st}")
