@@ -117,6 +117,20 @@ int mmsa_gemm_group_split(const mmsa_gemm_desc* d, int32_t n, float* ws, size_t 
 size_t mmsa_fp8_quantize_ws_bytes(void);
 int mmsa_fp8_quantize(const void* x_bf16, int64_t n, void* out_e4m3, float* scale, void* amax_ws, void* stream);
 int mmsa_gemm_fp8(const mmsa_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream);
+/* The forms the text encoder's forward uses (mmsa_bert_fwd with dtype MMSA_FP8):
+ * - mmsa_fp8_quantize_rows: per-TOKEN scales in ONE pass — row m of x [M][K] (bf16, row stride ldx elements, K % 8 == 0,
+ *   K <= 4096) becomes e4m3 bytes out[m][0..K) with row_scales[m] = max|x[m]| / 448 (2 B read + 1 B written per element, against
+ *   5 B and two launches for a per-tensor scale, which must see the whole tensor before it can convert);
+ * - mmsa_gemm_fp8_rows: mmsa_gemm_fp8 whose A operand carries those per-row scales (C[m][n] = epilogue(row_scales_a[m] *
+ *   scale_b[0] * sum_k ...));
+ * - mmsa_fp8_quantize_batch: per-tensor quantization of n <= 128 tensors of one bf16 buffer in TWO launches (the weights of every
+ *   quantized Linear, once per forward): tensor t = numel[t] elements at element offset offsets[t] (both % 8 == 0); its e4m3
+ *   bytes go to the same offset of out_e4m3, its scale to scales[t]; ws: mmsa_fp8_quantize_batch_ws_bytes(n) of device scratch. */
+int mmsa_fp8_quantize_rows(const void* x_bf16, int64_t ldx, int32_t M, int32_t K, void* out_e4m3, float* row_scales, void* stream);
+int mmsa_gemm_fp8_rows(const mmsa_gemm_desc* d, const float* row_scales_a, const float* scale_b, void* stream);
+size_t mmsa_fp8_quantize_batch_ws_bytes(int32_t n);
+int mmsa_fp8_quantize_batch(const void* base_bf16, const int64_t* offsets, const int64_t* numel, int32_t n, void* out_e4m3,
+                            float* scales, float* ws, void* stream);
 
 /* ---- LayerNorm (nn.LayerNorm: MultimodalModel.py:122,149 eps 1e-5; BERT eps 1e-12) ------------------------- */
 int mmsa_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,

@@ -101,6 +101,10 @@ def _declare(L):
         "mmsa_fp8_quantize_ws_bytes": (sz, []),
         "mmsa_fp8_quantize": (ctypes.c_int, [vp, i64, vp, vp, vp, vp]),
         "mmsa_gemm_fp8": (ctypes.c_int, [ctypes.POINTER(GemmDesc), vp, vp, vp]),
+        "mmsa_fp8_quantize_rows": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, vp]),
+        "mmsa_gemm_fp8_rows": (ctypes.c_int, [ctypes.POINTER(GemmDesc), vp, vp, vp]),
+        "mmsa_fp8_quantize_batch_ws_bytes": (sz, [i32]),
+        "mmsa_fp8_quantize_batch": (ctypes.c_int, [vp, vp, vp, i32, vp, vp, vp, vp]),
         "mmsa_layernorm_fwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
         "mmsa_layernorm_bwd_ws_bytes": (sz, [i32]),
         "mmsa_layernorm_bwd": (ctypes.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),

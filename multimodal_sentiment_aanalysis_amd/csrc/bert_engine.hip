@@ -79,8 +79,9 @@ struct BertWs {
   void *pooled, *dfeat_t, *dpool, *dprepool;
   void *bufA, *bufB, *bufC, *bufD, *bufI, *bufQ;
   void* ones8;  // [B*S][8] bf16 ones (grouped bias gradients, engine_common.h)
-  void *q_act, *q_w;     // fp8 mode: e4m3 copies of a Linear's input ([B*S][max(H, I)]) and weight ([max N*K])
-  float* q_scales;       // fp8 mode: [0] activation scale, [1] weight scale, [16...] the quantizer's partial-maximum scratch
+  void *q_act, *q_w;     // fp8 mode: e4m3 copy of a Linear's input ([B*S][max(H, I)]); e4m3 image of the whole weight table
+                         // (byte i = element i of the bf16 working copy; only the quantized Linears' ranges are written)
+  float *q_wscales, *q_rowscales, *q_batchws;  // per-tensor weight scales [4 * layers], per-token scales [B*S], quantizer scratch
   size_t colws_bytes;
   float *splitk, *colws, *lnws, *attnws;
   size_t splitk_bytes;
@@ -129,11 +130,13 @@ static BertWs bert_ws(const mmsa_bert_cfg& c, void* base) {
   w.colws = (float*)b.take(colb);
   w.colws_bytes = colb;
   w.ones8 = b.take(M * 8 * 2);
-  w.q_act = w.q_w = nullptr; w.q_scales = nullptr;
+  w.q_act = w.q_w = nullptr; w.q_wscales = w.q_rowscales = w.q_batchws = nullptr;
   if (c.dtype == MMSA_FP8) {
     w.q_act = b.take(M * (H > I ? H : I));
-    w.q_w = b.take((size_t)I * H > 3 * H * H ? (size_t)I * H : 3 * H * H);
-    w.q_scales = (float*)b.take(64 + fp8_quantize_ws_bytes());
+    w.q_w = b.take((size_t)bert_layout(c).t.total);
+    w.q_wscales = (float*)b.take((size_t)4 * c.layers * sizeof(float));
+    w.q_rowscales = (float*)b.take(M * sizeof(float));
+    w.q_batchws = (float*)b.take(fp8_quantize_batch_ws_bytes(FP8_BATCH_MAX));
   }
   w.lnws = (float*)b.take(layernorm_bwd_ws_bytes((int)H));
   w.attnws = (float*)b.take(attention_bwd_ws_bytes(c.batch, c.seq, c.heads));
@@ -191,31 +194,52 @@ int mmsa_bert_fwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
   auto W = [&](long off) { return (const void*)at(wt, off, es); };
   auto P = [&](long off) { return w32 + off; };
 
-  // fp8 mode: a Linear's input and weight are quantized (per-tensor scale from their own amax) right before its GEMM
-  const bool fp8 = c.dtype == MMSA_FP8;
-  auto lin = [&](const void* x, long ldx, long woff, const float* bias, void* y, long ldy, int Mr, int N, int K, int act,
+  // fp8 mode: the weights of the 4 Linears of every layer are quantized up front (per-tensor scales from their own amax; two
+  // launches for all of them), a Linear's input per token right before its GEMM (one pass)
+  bool fp8 = c.dtype == MMSA_FP8 && !Eng::force_simt();
+  if (fp8) {
+    std::vector<long> off, num;
+    for (int l = 0; l < c.layers; ++l) {
+      const BertLayerOff& f = lay.L[l];
+      const long o[4] = {f.wqkv, f.wo, f.w1, f.w2};
+      const long n[4] = {3L * H * H, (long)H * H, (long)I * H, (long)H * I};
+      for (int k = 0; k < 4; ++k) { off.push_back(o[k]); num.push_back(n[k]); }
+    }
+    for (size_t t0 = 0; t0 < off.size() && fp8; t0 += FP8_BATCH_MAX) {
+      const int cnt = (int)(off.size() - t0 < FP8_BATCH_MAX ? off.size() - t0 : FP8_BATCH_MAX);
+      const int rc = fp8_quantize_batch(wt, off.data() + t0, num.data() + t0, cnt, ws.q_w, ws.q_wscales + t0, ws.q_batchws, st);
+      if (rc == MMSA_ERR_ARG) fp8 = false;  // (a width that is not a multiple of 8: the bf16 path takes the whole forward)
+      else RET_IF(rc);
+    }
+  }
+  // (k = 0, 2: the input is a LayerNorm output whose per-token e4m3 image that LayerNorm wrote itself — no quantizer pass)
+  const bool ln_q = fp8 && !(H % 128) && !(getenv("MMSA_FP8_NO_LN_FUSE") && atoi(getenv("MMSA_FP8_NO_LN_FUSE")) != 0);
+  void* lnq = ln_q ? ws.q_act : nullptr;
+  float* lnqs = ln_q ? ws.q_rowscales : nullptr;
+  auto lin = [&](int l, int k, const void* x, long ldx, long woff, const float* bias, void* y, long ldy, int Mr, int N, int K, int act,
                  void* pre, const void* add, long ldadd, int pre_is_gelu_grad) -> int {
     if (fp8) {
-      const int rc = e.linear_fwd_fp8(x, ldx, W(woff), bias, y, ldy, Mr, N, K, act, pre, add, ldadd, pre_is_gelu_grad, ws.q_act,
-                                      ws.q_w, ws.q_scales);
+      const int rc = e.linear_fwd_fp8(x, ldx, (const char*)ws.q_w + woff, ws.q_wscales + 4 * l + k, bias, y, ldy, Mr, N, K, act, pre,
+                                      add, ldadd, pre_is_gelu_grad, ws.q_act, ws.q_rowscales, ln_q && (k == 0 || k == 2));
       if (rc != MMSA_ERR_UNSUPPORTED) return rc;
     }
     return e.linear_fwd(x, ldx, W(woff), bias, y, ldy, Mr, N, K, act, pre, add, ldadd, 0, pre_is_gelu_grad);
   };
   RET_IF(embed_gather(sdt(c), (const long long*)ids, W(lay.word), W(lay.pos), W(lay.type), ws.e, M, S, H, c.vocab, st));
-  RET_IF(layernorm_fwd(sdt(c), ws.e, P(lay.lnw), P(lay.lnb), ws.x0, ws.mean0, ws.rstd0, M, H, c.ln_eps, st));
+  RET_IF(layernorm_fwd(sdt(c), ws.e, P(lay.lnw), P(lay.lnb), ws.x0, ws.mean0, ws.rstd0, M, H, c.ln_eps, st, lnq, lnqs));
   const void* x = ws.x0;
   for (int l = 0; l < c.layers; ++l) {
     const BertLayerOff& f = lay.L[l];
     BertLayerWs& a = ws.L[l];
-    RET_IF(lin(x, H, f.wqkv, P(f.bqkv), a.qkv, 3 * H, M, 3 * H, H, MMSA_ACT_NONE, nullptr, nullptr, 0, 0));
+    RET_IF(lin(l, 0, x, H, f.wqkv, P(f.bqkv), a.qkv, 3 * H, M, 3 * H, H, MMSA_ACT_NONE, nullptr, nullptr, 0, 0));
     RET_IF(attention_fwd(aimpl, a.qkv, mask, a.ctx, c.batch, S, c.heads, 64, st));
-    RET_IF(lin(a.ctx, H, f.wo, P(f.bo), a.s1, H, M, H, H, MMSA_ACT_NONE, nullptr, x, H, 0));
-    RET_IF(layernorm_fwd(sdt(c), a.s1, P(f.ln1w), P(f.ln1b), a.h1, a.mean1, a.rstd1, M, H, c.ln_eps, st));
+    RET_IF(lin(l, 1, a.ctx, H, f.wo, P(f.bo), a.s1, H, M, H, H, MMSA_ACT_NONE, nullptr, x, H, 0));
+    RET_IF(layernorm_fwd(sdt(c), a.s1, P(f.ln1w), P(f.ln1b), a.h1, a.mean1, a.rstd1, M, H, c.ln_eps, st, lnq, lnqs));
     // a.pre receives gelu'(pre-activation): the factor the backward multiplies by (one exp / erf for both outputs)
-    RET_IF(lin(a.h1, H, f.w1, P(f.b1), a.act, I, M, I, H, MMSA_ACT_GELU, a.pre, nullptr, 0, gelu_factor()));
-    RET_IF(lin(a.act, I, f.w2, P(f.b2), a.s2, H, M, H, I, MMSA_ACT_NONE, nullptr, a.h1, H, 0));
-    RET_IF(layernorm_fwd(sdt(c), a.s2, P(f.ln2w), P(f.ln2b), a.out, a.mean2, a.rstd2, M, H, c.ln_eps, st));
+    RET_IF(lin(l, 2, a.h1, H, f.w1, P(f.b1), a.act, I, M, I, H, MMSA_ACT_GELU, a.pre, nullptr, 0, gelu_factor()));
+    RET_IF(lin(l, 3, a.act, I, f.w2, P(f.b2), a.s2, H, M, H, I, MMSA_ACT_NONE, nullptr, a.h1, H, 0));
+    RET_IF(layernorm_fwd(sdt(c), a.s2, P(f.ln2w), P(f.ln2b), a.out, a.mean2, a.rstd2, M, H, c.ln_eps, st,
+                         l + 1 < c.layers ? lnq : nullptr, lnqs));
     x = a.out;
   }
   // pooler on the first token of every sequence (row stride S*H), then the projection into the fusion width (fp32 out)

@@ -89,6 +89,23 @@ int mmsa_gemm_fp8(const mmsa_gemm_desc* d, const float* scale_a, const float* sc
   if (!d || !d->A || !d->B || !d->C || !scale_a || !scale_b) return MMSA_ERR_ARG;
   return gemm_fp8_launch(to_params(d), scale_a, scale_b, (hipStream_t)stream);
 }
+int mmsa_fp8_quantize_rows(const void* x_bf16, int64_t ldx, int32_t M, int32_t K, void* out_e4m3, float* row_scales, void* stream) {
+  return fp8_quantize_rows(x_bf16, (long)ldx, M, K, out_e4m3, row_scales, (hipStream_t)stream);
+}
+int mmsa_gemm_fp8_rows(const mmsa_gemm_desc* d, const float* row_scales_a, const float* scale_b, void* stream) {
+  if (!d || !d->A || !d->B || !d->C || !row_scales_a || !scale_b) return MMSA_ERR_ARG;
+  GemmParams p = to_params(d);
+  p.scale_a_rows = 1;
+  return gemm_fp8_launch(p, row_scales_a, scale_b, (hipStream_t)stream);
+}
+size_t mmsa_fp8_quantize_batch_ws_bytes(int32_t n) { return fp8_quantize_batch_ws_bytes(n); }
+int mmsa_fp8_quantize_batch(const void* base_bf16, const int64_t* offsets, const int64_t* numel, int32_t n, void* out_e4m3,
+                            float* scales, float* ws, void* stream) {
+  if (!offsets || !numel || n <= 0 || n > FP8_BATCH_MAX) return MMSA_ERR_ARG;
+  long off[FP8_BATCH_MAX], num[FP8_BATCH_MAX];
+  for (int t = 0; t < n; ++t) { off[t] = (long)offsets[t]; num[t] = (long)numel[t]; }
+  return fp8_quantize_batch(base_bf16, off, num, n, out_e4m3, scales, ws, (hipStream_t)stream);
+}
 
 int mmsa_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                        float* rstd, int32_t M, int32_t H, float eps, void* stream) {

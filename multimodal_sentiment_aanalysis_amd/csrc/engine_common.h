@@ -128,21 +128,24 @@ struct Eng {
     small_split(p);
     return gemm(p);
   }
-  // The same Linear with fp8 (e4m3) operands: x [M][K] and W [N][K] (both contiguous bf16) are quantized with per-tensor
-  // scales into q_act / q_w, then one fp8 MFMA GEMM with the usual epilogue. MMSA_ERR_UNSUPPORTED: caller falls back.
-  int linear_fwd_fp8(const void* x, long ldx, const void* W, const float* bias, void* y, long ldy, int M, int N, int K, int act,
-                     void* pre, const void* add, long ldadd, int pre_is_gelu_grad, void* q_act, void* q_w,
-                     float* q_scales) const {
-    if (dtype != MMSA_BF16 || force_simt() || ldx != K || !q_act || !q_w || !q_scales) return MMSA_ERR_UNSUPPORTED;
+  // The same Linear with fp8 (e4m3) operands: the input x [M][K] (bf16 rows, stride ldx) is quantized per ROW (one scale per
+  // token: fp8_quantize_rows, one pass) into q_act / q_row_scales; the weight comes already quantized (qW: e4m3 [N][K], per-tensor
+  // scale *w_scale — fp8_quantize_batch, once per forward for all Linears); then one fp8 MFMA GEMM with the usual epilogue.
+  // MMSA_ERR_UNSUPPORTED: caller falls back to bf16.
+  int linear_fwd_fp8(const void* x, long ldx, const void* qW, const float* w_scale, const float* bias, void* y, long ldy, int M,
+                     int N, int K, int act, void* pre, const void* add, long ldadd, int pre_is_gelu_grad, void* q_act,
+                     float* q_row_scales, bool prequantized = false) const {
+    if (dtype != MMSA_BF16 || force_simt() || !qW || !w_scale || !q_act || !q_row_scales || K > 4096 || (ldx % 8)) return MMSA_ERR_UNSUPPORTED;
     GemmParams p = blank();
-    p.A = q_act; p.lda = K; p.B = q_w; p.ldb = K; p.C = y; p.ldc = ldy;
+    p.A = q_act; p.lda = K; p.B = qW; p.ldb = K; p.C = y; p.ldc = ldy;
     p.M = M; p.N = N; p.K = K;
     p.bias = bias; p.act = act; p.C2 = pre; p.ldc2 = N; p.add = add; p.ldadd = ldadd;
     p.c2_gelu_grad = (pre && act == MMSA_ACT_GELU) ? pre_is_gelu_grad : 0;
+    p.scale_a_rows = 1;
     if (!gemm_fp8_eligible(p)) return MMSA_ERR_UNSUPPORTED;
-    RET_IF(fp8_quantize(x, (long)M * K, q_act, q_scales, (unsigned*)(q_scales + 16), st));
-    RET_IF(fp8_quantize(W, (long)N * K, q_w, q_scales + 1, (unsigned*)(q_scales + 16), st));
-    return gemm_fp8_launch(p, q_scales, q_scales + 1, st);
+    // (prequantized: the LayerNorm that produced x already wrote q_act / q_row_scales — layernorm_fwd's q_out)
+    if (!prequantized) RET_IF(fp8_quantize_rows(x, ldx, M, K, q_act, q_row_scales, st));
+    return gemm_fp8_launch(p, q_row_scales, w_scale, st);
   }
   // fp32 SIMT GEMMs of the fusion head have M = batch rows: a handful of workgroups each walking the whole K serially.
   // Split K over workgroups (the reducer applies the epilogue) so the launch is a few microseconds instead of ~25.

@@ -77,6 +77,7 @@ struct GemmParams {
   // in 2-byte units (K = values / 2), the result is scaled by scale_a[0] * scale_b[0] (device scalars). null: bf16 operands.
   const float* scale_a;
   const float* scale_b;
+  int scale_a_rows;  // scale_a holds one scale per ROW of A (per-token quantization, fp8_quantize_rows) instead of scale_a[0]
   // batch-row kernel only (gemm_f32_tiny.hip): B is a [K][1] column of ones that is never read (N must be 1): the product
   // is the column sum of the k-major A, i.e. a bias gradient as one more problem of a grouped launch
   int b_ones;

@@ -30,8 +30,8 @@
 
 struct Fp8Params {
   GemmParams g;           // M, N, K (in fp8 values), lda, ldb (bytes per row), C / epilogue fields as in gemm.h
-  const float* scale_a;   // device scalars
-  const float* scale_b;
+  const float* scale_a;   // device scalar, or one scale per row of A (g.scale_a_rows)
+  const float* scale_b;   // device scalar
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Params q) {
@@ -111,10 +111,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Params q) {
     __syncthreads();
   }
   // lane holds C[m = .. + r16][n = .. + 4 g + (0..3)] (swapped operands: D rows = n, columns = m)
-  const float alpha = q.scale_a[0] * q.scale_b[0];
+  const float sb = q.scale_b[0];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + r16;
+    const float alpha = (p.scale_a_rows ? (m < p.M ? q.scale_a[m] : 0.f) : q.scale_a[0]) * sb;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + 4 * g;
@@ -187,6 +188,154 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(const bf16* __restrict__
   }
 }
 
+// ---- per-row ("per-token") quantizer: ONE pass -----------------------------------------------------------------------------
+// A wave owns a row (K <= 64 * 8 * FP8_ROW_CHUNKS values): its lanes keep the row's 16-byte chunks in registers, take the row
+// maximum with DPP / shuffles and convert: 2 B read + 1 B written per element and one launch, against 5 B and two launches of the
+// per-tensor form (which has to know the whole tensor's maximum before it can convert anything). scales[m] = amax_m / 448.
+#define FP8_ROW_CHUNKS 8
+// ROWS rows per wave at a time, all of their loads issued before the first maximum is taken (K = 768 is 1.5 chunks per lane: with
+// one row per wave a lane had 1-2 loads in flight and the kernel ran at 1.9 TB/s)
+template <int NCH, int ROWS>
+__global__ __launch_bounds__(256) void fp8_quant_rows_kernel(const bf16* __restrict__ x, long ldx, int M, int K8,
+                                                             unsigned char* __restrict__ out, float* __restrict__ scales) {
+  const int lane = threadIdx.x & 63;
+  const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  if (m0 >= M) return;
+  bf16x8 v[ROWS][NCH];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      // unconditional loads (clamped chunk / row; masked where they are used): a branch around each load makes hipcc wait
+      // for every chunk separately — serial memory round trips (30 us instead of ~16 for a [16384][3072] activation)
+      const int ch = min(lane + 64 * c, K8 - 1);
+      const long row = min(m0 + r, (long)M - 1);
+      v[r][c] = *(const bf16x8*)(x + row * ldx + (long)ch * 8);
+    }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    if (m0 + r >= M) break;
+    float am = 0.f;
+    bool bad = false;  // (NaN / Inf: as fp8_amax_kernel, the row's scale becomes Inf and the Linear's output non-finite)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (lane + 64 * c < K8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = fabsf((float)v[r][c][e]);
+          bad |= !(a <= 3.0e38f);
+          am = fmaxf(am, a);
+        }
+      }
+    }
+    if (bad) am = __builtin_inff();
+    am = fmaxf(wave_max(am), 1e-20f);
+    const float inv = FP8_MAX / am;
+    if (lane == 0) scales[m0 + r] = am * (1.0f / FP8_MAX);
+    unsigned char* o = out + (m0 + r) * (long)K8 * 8;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < K8) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf((float)v[r][c][e] * inv, -FP8_MAX), FP8_MAX);
+        int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+        int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        typedef __attribute__((ext_vector_type(2))) int i32x2_;
+        *(i32x2_*)(o + (long)ch * 8) = i32x2_{lo, hi};
+      }
+    }
+  }
+}
+// x[M][K] bf16 (row stride ldx elements; K % 8 == 0, K <= 4096) -> out[M][K] e4m3 bytes (contiguous rows), scales[M]
+int fp8_quantize_rows(const void* x, long ldx, int M, int K, void* out, float* scales, hipStream_t st) {
+  if (!x || !out || !scales || M <= 0 || K <= 0 || (K % 8) || (ldx % 8) || K > 64 * 8 * FP8_ROW_CHUNKS) return MMSA_ERR_ARG;
+  const int K8 = K / 8, nch = cdiv(K8, 64);
+  const dim3 block(256);
+  const bf16* xp = (const bf16*)x;
+  unsigned char* op = (unsigned char*)out;
+  if (nch <= 2) hipLaunchKernelGGL((fp8_quant_rows_kernel<2, 4>), dim3(cdiv(M, 16)), block, 0, st, xp, ldx, M, K8, op, scales);
+  else if (nch <= 4) hipLaunchKernelGGL((fp8_quant_rows_kernel<4, 2>), dim3(cdiv(M, 8)), block, 0, st, xp, ldx, M, K8, op, scales);
+  else if (nch <= 6) hipLaunchKernelGGL((fp8_quant_rows_kernel<6, 2>), dim3(cdiv(M, 8)), block, 0, st, xp, ldx, M, K8, op, scales);
+  else hipLaunchKernelGGL((fp8_quant_rows_kernel<8, 1>), dim3(cdiv(M, 4)), block, 0, st, xp, ldx, M, K8, op, scales);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+// ---- per-tensor quantization of MANY tensors in two launches (the weights of every quantized Linear, once per forward) ------
+// Tensor t = n8[t] 16-byte chunks at element offset off[t] of one bf16 buffer; its e4m3 bytes go to the same element offset of
+// `out`, its scale to scales[t]. Same arithmetic as fp8_amax_kernel / fp8_quant_kernel; blockIdx.y = tensor.
+#define FP8_BATCH_PARTS 64
+struct Fp8Batch {
+  int n;
+  long off[FP8_BATCH_MAX], n8[FP8_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void fp8_amax_batch_kernel(const bf16* __restrict__ base, Fp8Batch tb, float* __restrict__ part) {
+  __shared__ float red[4];
+  const int t = blockIdx.y;
+  const bf16* x = base + tb.off[t];
+  const long n8 = tb.n8[t];
+  float m = 0.f;
+  bool bad = false;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const bf16x8 v = *(const bf16x8*)(x + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = fabsf((float)v[e]);
+      bad |= !(a <= 3.0e38f);
+      m = fmaxf(m, a);
+    }
+  }
+  if (bad) m = __builtin_inff();
+  m = block_max256(m, red);
+  if (threadIdx.x == 0) part[(long)t * FP8_BATCH_PARTS + blockIdx.x] = m;
+}
+__global__ __launch_bounds__(256) void fp8_quant_batch_kernel(const bf16* __restrict__ base, Fp8Batch tb, const float* __restrict__ part,
+                                                              unsigned char* __restrict__ out, float* __restrict__ scales) {
+  __shared__ float red[4];
+  const int t = blockIdx.y;
+  float am = threadIdx.x < FP8_BATCH_PARTS ? part[(long)t * FP8_BATCH_PARTS + threadIdx.x] : 0.f;
+  const float amax = fmaxf(block_max256(am, red), 1e-20f);
+  const float inv = FP8_MAX / amax;
+  if (blockIdx.x == 0 && threadIdx.x == 0) scales[t] = amax * (1.0f / FP8_MAX);
+  const bf16* x = base + tb.off[t];
+  unsigned char* o = out + tb.off[t];
+  const long n8 = tb.n8[t];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const bf16x8 v = *(const bf16x8*)(x + i * 8);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf((float)v[e] * inv, -FP8_MAX), FP8_MAX);
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    typedef __attribute__((ext_vector_type(2))) int i32x2_;
+    *(i32x2_*)(o + i * 8) = i32x2_{lo, hi};
+  }
+}
+size_t fp8_quantize_batch_ws_bytes(int n) { return (size_t)(n > 0 ? n : 1) * FP8_BATCH_PARTS * sizeof(float); }
+// n <= FP8_BATCH_MAX tensors of `base` (bf16): offsets / sizes in elements (both % 8 == 0); out: e4m3 bytes at the same offsets
+int fp8_quantize_batch(const void* base, const long* off, const long* numel, int n, void* out, float* scales, float* ws,
+                       hipStream_t st) {
+  if (!base || !off || !numel || !out || !scales || !ws || n <= 0 || n > FP8_BATCH_MAX) return MMSA_ERR_ARG;
+  Fp8Batch tb;
+  tb.n = n;
+  for (int t = 0; t < n; ++t) {
+    if (numel[t] <= 0 || (numel[t] % 8) || (off[t] % 8)) return MMSA_ERR_ARG;
+    tb.off[t] = off[t];
+    tb.n8[t] = numel[t] / 8;
+  }
+  hipLaunchKernelGGL(fp8_amax_batch_kernel, dim3(FP8_BATCH_PARTS, n), dim3(256), 0, st, (const bf16*)base, tb, ws);
+  hipLaunchKernelGGL(fp8_quant_batch_kernel, dim3(FP8_BATCH_PARTS, n), dim3(256), 0, st, (const bf16*)base, tb, (const float*)ws,
+                     (unsigned char*)out, scales);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
 size_t fp8_quantize_ws_bytes() { return FP8_PARTS * sizeof(float); }
 
 // x[n] bf16 (n % 8 == 0) -> out[n] e4m3 bytes, *scale = amax / 448; `amax_ws`: fp8_quantize_ws_bytes() of device scratch
@@ -208,6 +357,7 @@ bool gemm_fp8_eligible(const GemmParams& p) {
 }
 
 // p.A / p.B: e4m3 bytes (k-contiguous rows, lda / ldb in BYTES = fp8 elements); everything else as a bf16 NT GEMM of gemm.h
+// pin.scale_a_rows: scale_a holds one scale per row of A (fp8_quantize_rows) instead of one for the tensor
 int gemm_fp8_launch(const GemmParams& pin, const float* scale_a, const float* scale_b, hipStream_t st) {
   if (!gemm_fp8_eligible(pin) || !scale_a || !scale_b) return MMSA_ERR_UNSUPPORTED;
   Fp8Params q;

@@ -451,15 +451,18 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
 
   const int r16 = lane & 15, g4 = lane >> 4;
   float fp8_alpha = 1.f;
-  if constexpr (FP8) fp8_alpha = p.scale_a[0] * p.scale_b[0];
+  if constexpr (FP8) fp8_alpha = (p.scale_a_rows ? 1.f : p.scale_a[0]) * p.scale_b[0];
   auto epilogue = [&]() __attribute__((always_inline)) -> int {  // returns the store units it issued (0: it drained the queue)
     const int r16 = lane_ & 15, g4 = lane_ >> 4;  // (= the outer ones; re-derived so that they are not live across the K loop)
     const int mb = C.m0 + wm * 64 + r16, nb = C.n0 + wn * (NJ * 16) + 4 * g4;
     if constexpr (FP8) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        float al = fp8_alpha;  // scale_a[0] * scale_b[0], or (per-token scales) scale_b[0] alone times the row's own scale
+        if (p.scale_a_rows) al *= (mb + i * 16 < p.M) ? p.scale_a[mb + i * 16] : 0.f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] *= fp8_alpha;
+        for (int j = 0; j < NJ; ++j) acc[i][j] *= al;
+      }
     }
     if (s.split_k > 1) {  // raw fp32 partials -> slab sp
       const long slab = (long)C.sp * eM * eN;

@@ -9,6 +9,11 @@ int gemm_bf16_simt_launch(const GemmParams& p, hipStream_t st);
 // gemm_fp8.hip
 size_t fp8_quantize_ws_bytes();
 int fp8_quantize(const void* x_bf16, long n, void* out_e4m3, float* scale, unsigned* amax_ws, hipStream_t st);
+int fp8_quantize_rows(const void* x_bf16, long ldx, int M, int K, void* out_e4m3, float* scales, hipStream_t st);
+#define FP8_BATCH_MAX 128
+size_t fp8_quantize_batch_ws_bytes(int n);
+int fp8_quantize_batch(const void* base_bf16, const long* off, const long* numel, int n, void* out_e4m3, float* scales, float* ws,
+                       hipStream_t st);
 bool gemm_fp8_eligible(const GemmParams& p);
 int gemm_fp8_launch(const GemmParams& p, const float* scale_a, const float* scale_b, hipStream_t st);
 
@@ -16,7 +21,7 @@ int gemm_fp8_launch(const GemmParams& p, const float* scale_a, const float* scal
 int partial_finalize(const float* part, int nblk, long stride, int n, float* out, int accumulate, float scale,
                      hipStream_t st);
 int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                  int M, int H, float eps, hipStream_t st);
+                  int M, int H, float eps, hipStream_t st, void* q_out = nullptr, float* q_scales = nullptr);
 size_t layernorm_bwd_ws_bytes(int H);
 int layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                   void* dx, float* dgamma, float* dbeta, int accumulate, float* ws, int M, int H, hipStream_t st,

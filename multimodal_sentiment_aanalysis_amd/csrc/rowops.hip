@@ -14,7 +14,8 @@ template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            int M, int H, float eps) {
+                                                            int M, int H, float eps, unsigned char* __restrict__ q_out,
+                                                            float* __restrict__ q_scales) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nch = H >> 2;
   for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
@@ -53,6 +54,42 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
       if (ch < nch) Vec4<T>::store(yr + ch * 4, o);
+      v[c] = o;
+    }
+    // fp8 mode (gemm_fp8.hip): the row is in registers — its e4m3 image with the row's own scale (max |stored y| / 448) comes
+    // out of this pass instead of a quantizer pass over y (fp8_quant_rows_kernel's arithmetic on the bf16-ROUNDED values)
+    if (q_out) {
+      float am = 0.f;
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (lane + 64 * c < nch) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[c][e] = (float)(T)v[c][e];
+            const float a = fabsf(v[c][e]);
+            bad |= !(a <= 3.0e38f);
+            am = fmaxf(am, a);
+          }
+        }
+      }
+      if (bad) am = __builtin_inff();
+      am = fmaxf(wave_max(am), 1e-20f);
+      const float inv = 448.0f / am;
+      if (lane == 0) q_scales[row] = am * (1.0f / 448.0f);
+      unsigned char* qr = q_out + (long)row * H;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+          float f[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = fminf(fmaxf(v[c][e] * inv, -448.0f), 448.0f);
+          int pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+          pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
+          *(int*)(qr + ch * 4) = pk;
+        }
+      }
     }
   }
 }
@@ -255,16 +292,18 @@ int partial_finalize(const float* part, int nblk, long stride, int n, float* out
     else hipLaunchKernelGGL((KERNEL<T, 8>), __VA_ARGS__);                                         \
   } while (0)
 
+// q_out / q_scales (optional, bf16 only): also the per-token e4m3 image of y ([M][H] bytes) and its scales [M]
 int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                  int M, int H, float eps, hipStream_t st) {
+                  int M, int H, float eps, hipStream_t st, void* q_out, float* q_scales) {
   if (H % 4 || H > 2048) return MMSA_ERR_ARG;
+  if (q_out && (dtype != MMSA_BF16 || !q_scales)) return MMSA_ERR_ARG;
   const int grid = min(cdiv(M, 4), 4096);
   if (dtype == MMSA_BF16)
     LN_DISPATCH(layernorm_fwd_kernel, bf16, H, dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, mean,
-                rstd, M, H, eps);
+                rstd, M, H, eps, (unsigned char*)q_out, q_scales);
   else
     LN_DISPATCH(layernorm_fwd_kernel, float, H, dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y,
-                mean, rstd, M, H, eps);
+                mean, rstd, M, H, eps, (unsigned char*)nullptr, (float*)nullptr);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }

@@ -76,7 +76,31 @@ def fp8_quantize(x):
     return out, scale
 
 
-def gemm_fp8(Aq, sa, Bq, sb, C, bias=None, act=ACT_NONE, add=None, C2=None):
+def fp8_quantize_rows(x):
+    """x: [M, K] bf16 (row-contiguous view) -> (e4m3 bytes [M, K] uint8, per-row scales [M] fp32 = row amax / 448): one pass."""
+    L = _lib.load()
+    M, Kd = x.shape
+    out = torch.empty((M, Kd), dtype=torch.uint8, device=x.device)
+    scales = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(L.mmsa_fp8_quantize_rows(ptr(x), x.stride(0), M, Kd, ptr(out), ptr(scales), stream_ptr()), "mmsa_fp8_quantize_rows")
+    return out, scales
+
+
+def fp8_quantize_batch(base, offsets, numels):
+    """Per-tensor quantization of the tensors base[off : off + n] (a flat bf16 buffer) in two launches: (e4m3 image of `base` with
+    those ranges written, scales [len(offsets)])."""
+    L = _lib.load()
+    n = len(offsets)
+    out = torch.zeros(base.numel(), dtype=torch.uint8, device=base.device)
+    scales = torch.empty(n, dtype=torch.float32, device=base.device)
+    ws = torch.empty(L.mmsa_fp8_quantize_batch_ws_bytes(n), dtype=torch.uint8, device=base.device)
+    off = (ctypes.c_int64 * n)(*offsets)
+    num = (ctypes.c_int64 * n)(*numels)
+    check(L.mmsa_fp8_quantize_batch(ptr(base), off, num, n, ptr(out), ptr(scales), ptr(ws), stream_ptr()), "mmsa_fp8_quantize_batch")
+    return out, scales
+
+
+def gemm_fp8(Aq, sa, Bq, sb, C, bias=None, act=ACT_NONE, add=None, C2=None, row_scales=False):
     """C[M,N] = epilogue(sa * sb * Aq[M,K] Bq[N,K]^T) on e4m3 bytes (mmsa_gemm_fp8). Returns the status (3 = unsupported shape)."""
     L = _lib.load()
     M, Kd = Aq.shape
@@ -93,6 +117,8 @@ def gemm_fp8(Aq, sa, Bq, sb, C, bias=None, act=ACT_NONE, add=None, C2=None):
     d.ldc2 = N
     d.out_f32 = int(C.dtype == torch.float32)
     d.split_k = 1
+    if row_scales:  # sa: one scale per row of Aq (fp8_quantize_rows)
+        return L.mmsa_gemm_fp8_rows(ctypes.byref(d), ptr(sa), ptr(sb), stream_ptr())
     return L.mmsa_gemm_fp8(ctypes.byref(d), ptr(sa), ptr(sb), stream_ptr())
 
 

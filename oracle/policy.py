@@ -15,12 +15,13 @@ Three refinements over round 1:
     rounding (two correct bf16 forwards differ by 1-ulp flips that decorrelate within a few layers), and a wrong
     backward kernel cannot hide behind a loose tolerance.
   * `trace={}`: collects every named activation (for tests that look at intermediate tensors).
-  * `fp8="tensor"` (BF16G_FP8, BASELINE.json configs[4]): the text encoder's four forward Linears per layer take e4m3 operands —
-    activation and weight are each scaled by 448 / amax (amax over the whole bf16-stored tensor: "current" per-tensor scaling),
-    rounded to OCP e4m3 (torch.float8_e4m3fn = round-to-nearest-even, what v_cvt_pk_fp8_f32 does), multiplied exactly and
-    rescaled: csrc/gemm_fp8.hip restated. The backward is the bf16 one (straight-through: gradients use the UNQUANTIZED bf16
-    operands, as the device's backward does). `fp8="row"`: one scale per activation ROW (token) and per weight ROW (output
-    feature) — the scaling the LayerNorm-fused quantizer produces.
+  * `fp8="token"` (BF16G_FP8, BASELINE.json configs[4]): the text encoder's four forward Linears per layer take e4m3 operands —
+    the activation is scaled per TOKEN (row) by 448 / row amax, the weight per TENSOR by 448 / amax (amax over the bf16-stored
+    values: "current" scaling), both rounded to OCP e4m3 (torch.float8_e4m3fn = round-to-nearest-even, what v_cvt_pk_fp8_f32
+    does), multiplied exactly and rescaled: csrc/gemm_fp8.hip (fp8_quant_rows_kernel, fp8_quant_batch_kernel) restated. The
+    backward is the bf16 one (straight-through: gradients use the UNQUANTIZED bf16 operands, as the device's backward does).
+    `fp8="tensor"`: both operands per tensor (the stand-alone mmsa_fp8_quantize + mmsa_gemm_fp8 pair); `fp8="row"`: one scale
+    per activation row and per weight row (output feature).
 """
 import torch
 
@@ -66,7 +67,7 @@ class _Force(torch.autograd.Function):
 FP8_MAX = 448.0
 
 
-def e4m3_quantize(x, per_row):
+def e4m3_quantize(x, per_row):  # per_row: one scale per row of the last dimension (a token / an output feature)
     """(q, scale): q = e4m3(x * 448 / amax) as fp32 values, scale = amax / 448 (amax over the tensor, or over each row);
     the expressions of csrc/gemm_fp8.hip::fp8_quant_kernel (inv = 448 / amax in fp32, clamp, RNE conversion)."""
     a = x.abs().amax(dim=-1, keepdim=True) if per_row else x.abs().amax()
@@ -80,12 +81,12 @@ class _Fp8Linear(torch.autograd.Function):
     """forward: (q_x q_w^T) * scale_x * scale_w; backward: straight-through with the unquantized operands."""
 
     @staticmethod
-    def forward(ctx, x, w, per_row):
-        qx, sx = e4m3_quantize(x, per_row)
-        qw, sw = e4m3_quantize(w, per_row)
+    def forward(ctx, x, w, mode):
+        qx, sx = e4m3_quantize(x, mode in ("row", "token"))
+        qw, sw = e4m3_quantize(w, mode == "row")
         ctx.save_for_backward(x, w)
         y = qx @ qw.t()
-        return y * sx * (sw.t() if per_row else sw)
+        return y * sx * (sw.t() if mode == "row" else sw)
 
     @staticmethod
     def backward(ctx, g):
@@ -95,7 +96,7 @@ class _Fp8Linear(torch.autograd.Function):
 
 class Policy:
     def __init__(self, storage="fp32", round_grads=False, forced=None, trace=None, fp8=None):
-        assert storage in ("fp32", "bf16") and fp8 in (None, "tensor", "row")
+        assert storage in ("fp32", "bf16") and fp8 in (None, "tensor", "row", "token")
         assert fp8 is None or storage == "bf16"
         self.storage, self.round_grads, self.forced, self.trace, self.fp8 = storage, round_grads, forced, trace, fp8
         self.local_err = {}  # forcing: relative L2 distance of each forced tensor from the value computed from its forced inputs
@@ -118,7 +119,7 @@ class Policy:
         fp8 configuration quantizes; plain product otherwise."""
         if self.fp8 is None:
             return x @ w.t()
-        return _Fp8Linear.apply(x, w, self.fp8 == "row")
+        return _Fp8Linear.apply(x, w, self.fp8)
 
     def qw(self, w):
         """The working copy of a WEIGHT in the storage type: forward rounding only (weight gradients are fp32)."""
@@ -128,4 +129,4 @@ class Policy:
 FP32 = Policy("fp32")
 BF16 = Policy("bf16")
 BF16G = Policy("bf16", round_grads=True)
-BF16G_FP8 = Policy("bf16", round_grads=True, fp8="tensor")
+BF16G_FP8 = Policy("bf16", round_grads=True, fp8="token")  # what mmsa_bert_fwd does in fp8 mode: per-token x, per-tensor W

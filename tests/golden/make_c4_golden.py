@@ -6,7 +6,7 @@ a few minutes of CPU):
 
   fp32        the reference arithmetic;
   bf16        bf16 storage at the points where the HIP path stores bf16 (oracle/policy.py BF16G);
-  fp8         bf16 storage + e4m3 operands with per-tensor current scaling in the text encoder's four forward Linears per layer
+  fp8         bf16 storage + e4m3 operands (per-token activation scales, per-tensor weight scales, current scaling) in the text encoder's four forward Linears per layer
               (BF16G_FP8: csrc/gemm_fp8.hip restated) — what precision="fp8" computes.
 
 Weights are regenerated from seed 1234 by the product's initialisers on both sides (as make_c0_golden.py), the batch from

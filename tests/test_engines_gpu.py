@@ -937,17 +937,23 @@ def test_fp8_linear_propagates_non_finite_inputs(dev):
     w = torch.randn(128, 256, device=dev).bfloat16()
     wq, sw = K.fp8_quantize(w)
 
-    def linear(xin):
-        xq, sx = K.fp8_quantize(xin)
+    def linear(xin, rows):
+        xq, sx = K.fp8_quantize_rows(xin) if rows else K.fp8_quantize(xin)
         y = torch.empty(256, 128, dtype=torch.bfloat16, device=dev)
-        assert K.gemm_fp8(xq, sx, wq, sw, y) == 0
+        assert K.gemm_fp8(xq, sx, wq, sw, y, row_scales=rows) == 0
         return y.float()
 
-    assert torch.isfinite(linear(x)).all()
-    for bad in (float("nan"), float("inf"), float("-inf")):
-        xb = x.clone()
-        xb[17, 3] = bad
-        assert not torch.isfinite(linear(xb)).all(), f"{bad} was laundered into finite values"
+    for rows in (False, True):  # per-tensor scale; per-token scales (the engine's form: only the faulty token's row goes non-finite)
+        assert torch.isfinite(linear(x, rows)).all()
+        for bad in (float("nan"), float("inf"), float("-inf")):
+            xb = x.clone()
+            xb[17, 3] = bad
+            assert not torch.isfinite(linear(xb, rows)).all(), f"{bad} was laundered into finite values (rows={rows})"
+    wb = w.clone()
+    wb[5, 9] = float("nan")
+    flat = torch.cat([w.reshape(-1), wb.reshape(-1)])
+    img, sc = K.fp8_quantize_batch(flat, [0, w.numel()], [w.numel(), w.numel()])
+    assert torch.isfinite(sc[0]) and not torch.isfinite(sc[1]), "a non-finite weight must make its tensor's scale non-finite"
 
 
 @pytest.mark.parametrize("precision,pol,tol_f,tol_g", [("fp32", FP32, 5e-5, 5e-4), ("bf16", BF16G, 2e-2, 8e-2)])

@@ -227,6 +227,51 @@ def test_gemm_fp8(dev, M, N, Kd):
     assert ((Cf.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 1e-4
 
 
+@pytest.mark.parametrize("M,N,Kd", [(256, 256, 128), (1024, 768, 768), (300, 136, 256), (8192, 768, 3072), (77, 260, 384), (512, 1024, 4096)])
+def test_gemm_fp8_per_token_scales(dev, M, N, Kd):
+    """The forms the text encoder's forward uses: per-TOKEN activation scales in one pass (mmsa_fp8_quantize_rows), per-tensor
+    weight scales for many tensors in two launches (mmsa_fp8_quantize_batch), and the NT GEMM whose A operand carries one scale
+    per row (mmsa_gemm_fp8_rows). Bytes = torch's float8_e4m3fn rounding of x / scale; GEMM = float64 product of the dequantized
+    operands. Rows of A are a strided view (the engine quantizes column slices of wider buffers)."""
+    wide = rnd((M, Kd + 64), torch.bfloat16, dev, 1)
+    wide[:, 7] *= 30.0  # rows with very different ranges: what per-token scales are for
+    wide[3] *= 0.01
+    A = wide[:, :Kd]
+    Aq, sa = K.fp8_quantize_rows(A)
+    amax = A.float().abs().amax(dim=1)
+    assert torch.allclose(sa, amax / 448.0, rtol=1e-6, atol=0)
+    inv = torch.tensor(448.0, device=dev) / amax  # the kernel's own expression (x * (448 / amax), clamp, round to nearest even)
+    want = (A.float() * inv[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    frac = (want != Aq).float().mean().item()
+    assert frac < 1e-4, f"row quantizer differs from torch's e4m3 rounding on {frac:.3%} of the elements"
+    # three weights inside one flat buffer, quantized together
+    flat = rnd((3 * N * Kd + 64,), torch.bfloat16, dev, 2, 0.05)
+    offs = [0, N * Kd + 32, 2 * N * Kd + 64]
+    flat[offs[1]:offs[1] + N * Kd] *= 4.0
+    img, sb = K.fp8_quantize_batch(flat, offs, [N * Kd] * 3)
+    for t, off in enumerate(offs):
+        w = flat[off:off + N * Kd].float()
+        assert abs(sb[t].item() - w.abs().max().item() / 448.0) <= 1e-6 * w.abs().max().item()
+        want = (w * (torch.tensor(448.0, device=dev) / w.abs().max())).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+        frac = (want != img[off:off + N * Kd]).float().mean().item()
+        assert frac < 1e-4, f"batch quantizer, tensor {t}: {frac:.3%} of the bytes differ"
+    Bq = img[offs[1]:offs[1] + N * Kd].view(N, Kd)
+    Ad = Aq.view(torch.float8_e4m3fn).float().cpu().double() * sa.cpu().double()[:, None]
+    Bd = Bq.view(torch.float8_e4m3fn).float().cpu().double() * sb[1].item()
+    ref = Ad @ Bd.T
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    assert K.gemm_fp8(Aq, sa, Bq, sb[1:2], C, row_scales=True) == 0
+    assert_close(C, ref, torch.bfloat16, "fp8 NT, per-token scales")
+    bias = rnd((N,), torch.float32, dev, 3)
+    add = rnd((M, N), torch.bfloat16, dev, 4)
+    assert K.gemm_fp8(Aq, sa, Bq, sb[1:2], C, bias=bias, act=ACT_GELU, add=add, row_scales=True) == 0
+    assert_close(C, F.gelu(ref + bias.cpu().double()) + add.cpu().double(), torch.bfloat16, "fp8 per-token bias+gelu+residual")
+    # per-token scales keep a small-range row's precision: row 3 (1 % of the others' range) against the exact bf16 product
+    exact = A.cpu().double() @ (flat[offs[1]:offs[1] + N * Kd].view(N, Kd).cpu().double()).T
+    rel3 = ((ref[3] - exact[3]).norm() / exact[3].norm()).item()
+    assert rel3 < 0.08, rel3
+
+
 CONVS = [  # B, H, W, Cin, Cout, k, stride, pad
     (2, 8, 8, 64, 64, 3, 1, 1),
     (2, 9, 7, 64, 128, 3, 2, 1),
