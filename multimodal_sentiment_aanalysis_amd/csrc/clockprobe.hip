@@ -29,7 +29,11 @@ __global__ __launch_bounds__(256) void mfma_clock_probe_kernel(int iters, unsign
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int k = 0; k < 16; ++k)
+#ifdef PROBE_VGPR_ACC  // experiment: accumulators in ArchVGPRs (what hipcc picks for the GEMM kernels) instead of AccVGPRs
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a[k >> 2]), "v"(b[k & 3]));
+#else
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[k]) : "v"(a[k >> 2]), "v"(b[k & 3]));
+#endif
   }
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // MFMA result -> VALU read: the wait states hipcc would have inserted itself
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();

@@ -38,6 +38,11 @@
 #endif
 
 #define G2_MAX_GROUPS GEMM_MAX_GROUPS
+#ifdef G2_NO_SETPRIO  // experiment (tools/microbench/build_variant.sh -DG2_NO_SETPRIO): no priority raise around the MFMA blocks
+#define G2_SETPRIO(x) ((void)0)
+#else
+#define G2_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 struct G2Sched {
   int ntm, ntn, ntiles;  // tile grid
   int split_k, per;      // K splits; K steps per split
@@ -823,13 +828,13 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     }
   };
   auto mma_half = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[NJ]) __attribute__((always_inline)) {
-    __builtin_amdgcn_s_setprio(1);
+    G2_SETPRIO(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = mma1(fb[j], fa[i], acc[i][j]);
     mma_colsum(fa);
-    __builtin_amdgcn_s_setprio(0);
+    G2_SETPRIO(0);
   };
   // the same 4 x NJ MFMAs with half of the LDS-DMA instructions of a K step spread between them. The refill of the
   // stage freed by the mid-step barrier of step u (= the DMA of step u+3) is issued in two parts: pieces 0..2 in the
@@ -842,7 +847,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     constexpr int GAP = (4 * NJ) / (P1 - P0 > 0 ? (P1 - P0) : 1);        // MFMAs between two DMA instructions
     if constexpr (PART == 0) dma_begin();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    G2_SETPRIO(1);
     auto one = [&](auto idx_c) __attribute__((always_inline)) {
       constexpr int idx = decltype(idx_c)::value;
       constexpr int i = idx / NJ, j = idx % NJ;
@@ -868,7 +873,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       one(std::integral_constant<int, 14>{}); one(std::integral_constant<int, 15>{});
     }
     mma_colsum(fa);
-    __builtin_amdgcn_s_setprio(0);
+    G2_SETPRIO(0);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (PART == 1) dma_advance();
   };
@@ -969,19 +974,19 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     };
     auto mma16 = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[4], auto jh_c) __attribute__((always_inline)) {
       constexpr int jh = decltype(jh_c)::value;
-      __builtin_amdgcn_s_setprio(1);
+      G2_SETPRIO(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][jh * 4 + j] = mma1(fb[j], fa[i], acc[i][jh * 4 + j]);
-      __builtin_amdgcn_s_setprio(0);
+      G2_SETPRIO(0);
     };
     // eight MFMAs of sub-phase (1,1) (row tiles I0, I0 + 1) with the four LDS-DMA instructions of one unit between them
     auto mma8_dma = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[4], auto i0_c, auto isB_c, int slot) __attribute__((always_inline)) {
       constexpr int I0 = decltype(i0_c)::value;
       constexpr bool ISB = decltype(isB_c)::value != 0;
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+      G2_SETPRIO(1);
       auto one = [&](auto idx_c) __attribute__((always_inline)) {
         constexpr int idx = decltype(idx_c)::value;
         constexpr int i = I0 + idx / 4, j = idx % 4;
@@ -997,17 +1002,17 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
       one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
       one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
-      __builtin_amdgcn_s_setprio(0);
+      G2_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
     };
     auto mma8 = [&](const bf16x8(&fa)[4], const bf16x8(&fb)[4], auto i0_c) __attribute__((always_inline)) {
       constexpr int I0 = decltype(i0_c)::value;
-      __builtin_amdgcn_s_setprio(1);
+      G2_SETPRIO(1);
 #pragma unroll
       for (int i = I0; i < I0 + 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][4 + j] = mma1(fb[j], fa[i], acc[i][4 + j]);
-      __builtin_amdgcn_s_setprio(0);
+      G2_SETPRIO(0);
     };
     // prologue: A(0) B(0) A(1) B(1) A(2)
     unitA(); unitB();
