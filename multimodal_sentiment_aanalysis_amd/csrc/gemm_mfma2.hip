@@ -134,7 +134,12 @@ __device__ __forceinline__ float row16_sum(float v) {
 // epilogue's ~60 extra live registers made the allocator spill LOOP-CARRIED values of kernels that never execute it — the grouped
 // weight-gradient kernel went from 177 to 492 us when two more arrays were added to an epilogue it does not use — and every
 // scratch reload in the K loop waits vmcnt(0), i.e. drains the LDS-DMA ring.
-template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8 = false, bool GEN = true>
+// EPI (the GEN parameter refined): 0 = no general epilogue (plain / slab stores only); 1 = the general epilogue with every
+// option decided at run time; 2-5 = the same code with the options fixed at compile time for the launches that dominate the step:
+//   2 bias (+ nothing else), 3 bias + GELU + gelu' side output (FFN-up), 4 (bias +) residual add, 5 (bias +) x gelu' factor.
+// The fully general instantiation is ~27 000 instructions = 156 KiB of code against 12 KiB for EPI 0 (the shared instruction
+// cache holds 64 KiB): every tile's epilogue streamed tens of KiB of mostly not-taken branches through it and evicted the K loop.
+template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8 = false, int EPI = 1>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) {
   // The body is compiled in the device pass only: hipcc's HOST pass (ROCm 7.2) silently fails to instantiate this
   // template when it sees the body (no diagnostic, the launch stub stays an undefined symbol of the .so).
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       }
       return (p.out_f32 ? 2 : 1) * (BIG ? 2 : 1);
     }
-    if constexpr (!GEN) {  // (not reached: the launcher gives a non-plain epilogue the GEN instantiation)
+    if constexpr (EPI == 0) {  // (not reached: the launcher gives a non-plain epilogue an instantiation that has one)
       wait_vm<0>();
       return 0;
     } else {
@@ -580,7 +585,16 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
     // see an empty queue. All side-operand loads of the tile are issued up front, branch-free through buffer
     // descriptors (out-of-range lanes read 0), and awaited once: as a per-sub-tile load -> use -> store chain it cost
     // 16 dependent memory round trips per tile (FFN GEMMs ran at 420-470 TF/s against 750 for the plain store).
-    if (!(p.out_f32 && p.accumulate)) {
+    // the options: run-time values in the general instantiation, compile-time constants in the specialised ones
+    constexpr bool EG = EPI == 1;
+    const bool o_rmw = EG && p.out_f32 && p.accumulate;                 // fp32 read-modify-write (rare)
+    const bool o_c2gelu = EG ? (p.C2 && p.c2_gelu_grad) : EPI == 3;      // side output = gelu'(pre-activation), output = gelu
+    const bool o_c2plain = EG && p.C2 && !p.c2_gelu_grad;               // side output = pre-activation
+    const bool o_act = EG && p.act != MMSA_ACT_NONE;                    // any other activation
+    const bool o_mulfac = EG ? p.mul_is_factor != 0 : true;
+    const bool o_outf32 = EG && p.out_f32;
+    const bool o_act_after = EG && p.act_after_add;
+    if (!o_rmw) {
       // The 256 x 256 tile (NJ = 8) runs this epilogue in two passes of four column tiles each: with all eight at once the side
       // operands (64 VGPRs) and biases (32) on top of 128 accumulators and the loop's prefetched fragments spilled ~500 VGPRs.
       constexpr int JW = BIG ? 4 : NJ;
@@ -592,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       // gelu' operand, or the residual when there is no gelu' operand (both: a second batch). The 256 x 256 tile takes no side
       // operands (the planner keeps such problems on the smaller tiles): 128 accumulators leave no room for them
       i32x2 side[BIG ? 1 : 4][BIG ? 1 : JW];
-      const bool has_mul = !BIG && p.mul != nullptr, has_add = !BIG && p.add != nullptr;
+      const bool has_mul = !BIG && (EG ? p.mul != nullptr : EPI == 5), has_add = !BIG && (EG ? p.add != nullptr : EPI == 4);
       auto load_side = [&](const void* ptr, long ld) __attribute__((always_inline)) {
         if constexpr (!BIG) {
           __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, (int)((cext * ld + p.N) * 2), 0x00020000);
@@ -620,7 +634,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
                      // so the epilogue ends with a known number of outstanding operations and needs no trailing drain
                      // (the drain made each tile wait for its own stores: +10 us on a bias-only 8192x3072x768 GEMM)
       __builtin_amdgcn_sched_barrier(0);
-      __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(p.C2, 0, p.C2 ? (int)((cext * p.ldc2 + p.N) * 2) : 0, 0x00020000);
+      __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(p.C2, 0, (o_c2gelu || o_c2plain) ? (int)((cext * p.ldc2 + p.N) * 2) : 0, 0x00020000);
       const int mrow = mb + ((g4 & 1) << 4), ncol = C.n0 + wn * (NJ * 16) + ((g4 >> 1) << 3);
       auto unpack = [&](i32x2 v) __attribute__((always_inline)) -> f32x4 {
         const bf16x4 t = __builtin_bit_cast(bf16x4, v);
@@ -643,7 +657,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
           const int j = J0 + jj;
 #pragma unroll
           for (int h = 0; h < 2; ++h) acc[i + h][j] += bias4[jj];
-          if (p.C2 && p.c2_gelu_grad) {  // side output = gelu'(pre-activation), from the same exp / erf as the activation
+          if (o_c2gelu) {  // side output = gelu'(pre-activation), from the same exp / erf as the activation
             f32x4 d0, d1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -653,8 +667,8 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
             }
             store_pair(rc2, p.ldc2, mrow + i * 16, ncol + j * 16, d0, d1);
           } else {
-            if (p.C2) store_pair(rc2, p.ldc2, mrow + i * 16, ncol + j * 16, acc[i][j], acc[i + 1][j]);
-            if (p.act != MMSA_ACT_NONE && !p.act_after_add) {
+            if (o_c2plain) store_pair(rc2, p.ldc2, mrow + i * 16, ncol + j * 16, acc[i][j], acc[i + 1][j]);
+            if (o_act && !o_act_after) {
 #pragma unroll
               for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -665,7 +679,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
           for (int h = 0; h < 2; ++h) {
             if (has_mul) {
               const f32x4 x = unpack(side[BIG ? 0 : i + h][BIG ? 0 : jj]);
-              if (p.mul_is_factor) acc[i + h][j] *= x;
+              if (o_mulfac) acc[i + h][j] *= x;
               else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i + h][j][r] *= gelu_erf_grad(x[r]);
@@ -691,13 +705,13 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
 #pragma unroll
             for (int h = 0; h < 2; ++h) acc[i + h][j] += unpack(side[BIG ? 0 : i + h][BIG ? 0 : jj]);
           }
-          if (p.act != MMSA_ACT_NONE && p.act_after_add) {
+          if (o_act && o_act_after) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
               for (int r = 0; r < 4; ++r) acc[i + h][j][r] = apply_act(acc[i + h][j][r], p.act);
           }
-          if (p.out_f32) {
+          if (o_outf32) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               const int m = mb + (i + h) * 16, n = nb + j * 16;
@@ -711,7 +725,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       }
       // outstanding now: the C stores (bf16 pairs: 2 JW instructions; fp32: 4 JW) and, unless a second load batch was
       // awaited after them, the side-output stores (2 JW). In units of NSU (2 NJ; the 256 x 256 tile counts in units of NJ = 2 JW):
-      units = (p.out_f32 ? 2 : 1) + ((p.C2 && !(has_mul && has_add)) ? 1 : 0);
+      units = (o_outf32 ? 2 : 1) + (((o_c2gelu || o_c2plain) && !(has_mul && has_add)) ? 1 : 0);
       };
       part(std::integral_constant<int, 0>{});
       if constexpr (BIG) {
@@ -1259,6 +1273,24 @@ static inline int g2_epi_class(const GemmParams& p) {
   return (p.mul || p.add) ? 2 : (p.bias || p.C2 || p.act != MMSA_ACT_NONE || (p.out_f32 && p.accumulate)) ? 1 : 0;
 }
 
+// Which epilogue instantiation a non-plain launch takes (gemm2_kernel's EPI): 2-5 = the specialised ones, which exist for the
+// plain (no gather) NT / NN problems; 1 = the general one. (0, the plain / slab store, is decided by the launcher.)
+static inline int g2_epi_kind(const GemmParams& p) {
+  static const bool off = [] { const char* v = getenv("MMSA_G2_NO_EPI_SPEC"); return v && atoi(v) != 0; }();  // A/B hook
+  if (off || p.a_kmajor || p.gather) return 1;
+  if (p.out_f32 || p.act_after_add || (p.C2 && !p.c2_gelu_grad)) return 1;
+  if (!p.mul && !p.add) {
+    if (p.b_kmajor) return 1;
+    if (!p.C2 && p.act == MMSA_ACT_NONE) return 2;
+    if (p.C2 && p.c2_gelu_grad && p.act == MMSA_ACT_GELU) return 3;
+    return 1;
+  }
+  if (p.C2 || p.act != MMSA_ACT_NONE) return 1;
+  if (p.add && !p.mul) return 4;
+  if (p.mul && p.mul_is_factor && !p.add && p.b_kmajor) return 5;
+  return 1;
+}
+
 struct G2Plan { int wm, nj, split; };  // wave rows (4: 256-row tile, 2: 128-row tile), column tiles per wave, K split
 static inline int g2_bm(const G2Plan& pl) { return pl.wm * 64; }
 static inline int g2_bn(const G2Plan& pl) { return pl.nj * 16 * (8 / pl.wm); }
@@ -1331,7 +1363,12 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
     // compiler spills ~60 VGPRs there), measured +3 / +8 us per item (tools/microbench/bench_small.py, bench_epi2.py)
     // (r3, tools/microbench/bench_epi2.py on 8192x3072x768: bias + GELU + side output 94.8 us on the 256x128 tile against 82.0 on
     //  256x96, bias alone 65.7 / 57.9 — the 128-wide general epilogue is the one that spills; its price went up accordingly)
-    static const double epi_cost[3][6] = {{0, 0, 0, 0, 0, 0}, {6.0, 1.0, 0.9, 0.65, 0.5, 4.0}, {12.0, 2.0, 1.2, 1.0, 0.8, 10.0}};
+    // (r3: the specialised epilogues — g2_epi_kind 2, 4, 5 — do not spill on the 256x128 tile; in situ the x gelu' data gradient
+    //  8192x3072x768 runs 58.7 us there against 64.3 on 256x96, the residual-add 1x1 data gradients 3-14 % faster)
+    static const double epi_cost_gen[3][6] = {{0, 0, 0, 0, 0, 0}, {6.0, 1.0, 0.9, 0.65, 0.5, 4.0}, {12.0, 2.0, 1.2, 1.0, 0.8, 10.0}};
+    static const double epi_cost_spec[2][6] = {{1.0, 1.0, 0.9, 0.65, 0.5, 4.0}, {2.0, 2.0, 1.2, 1.0, 0.8, 10.0}};
+    const int kind = epi ? g2_epi_kind(p) : 0;
+    const double* epi_cost_row = (kind == 2) ? epi_cost_spec[0] : (kind == 4 || kind == 5) ? epi_cost_spec[1] : epi_cost_gen[epi];
     static const bool no_epi = [] { const char* v = getenv("MMSA_G2_NOEPI"); return v && atoi(v) != 0; }();  // A/B hook
     const double waste = (double)ntn * bn / p.N * ((double)ntm * bm / p.M);  // padding: only as a tie breaker
     for (int c = 0; c < nc; ++c) {
@@ -1340,7 +1377,7 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
       const long items = tiles * split;
       const long rounds = (items + cus - 1) / cus;
       // (with a K split the tiles store raw slabs and the reducer applies the epilogue)
-      double cost = (double)rounds * (per * t_step + t_item + (split == 1 && !no_epi ? epi_cost[epi][ci] : 0.0)) + 1e-3 * waste;
+      double cost = (double)rounds * (per * t_step + t_item + (split == 1 && !no_epi ? epi_cost_row[ci] : 0.0)) + 1e-3 * waste;
       if (split > 1) cost += mdl.c_split + mdl.d_split * split * (double)p.M * p.N * 4.0 / 4e6;
       if (cost < best_cost - 1e-9) { best_cost = cost; best = G2Plan{shape.wm, shape.nj, split}; }
     }
@@ -1350,9 +1387,9 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
 
 // plans are pure functions of the shape: memoize (one caller thread per process — include/mmsa.h)
 static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
-  struct Key { int M, N, K, epi, big_ok; size_t ws; G2Plan plan; };
+  struct Key { int M, N, K, epi, big_ok; size_t ws; G2Plan plan; };  // (epi: class * 8 + kind)
   static std::vector<Key> cache;
-  const int epi = g2_epi_class(p);
+  const int epi = g2_epi_class(p) * 8 + (g2_epi_class(p) ? g2_epi_kind(p) : 0);
   const int big_ok = !(p.gather || p.scale_a || p.c_gw > 0 || p.colstat || p.mul || p.add || p.a_kmajor);  // which tile shapes exist
   for (const Key& k : cache)
     if (k.M == p.M && k.N == p.N && k.K == p.K && k.epi == epi && k.big_ok == big_ok && k.ws == ws_bytes_avail) return k.plan;
@@ -1361,24 +1398,36 @@ static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
   return plan;
 }
 
-template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8, bool GEN>
+template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8, int EPI>
 static int g2_launch_e(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8, GEN>,
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8, EPI>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, NJ == 8 ? 163840 : G2_LDS);
     attr_set = true;
   }
   // (the 256 x 256 tile takes all 160 KiB of LDS: five 32 KiB slots)
-  hipLaunchKernelGGL((gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8, GEN>), dim3(grid), dim3(512), NJ == 8 ? 163840 : G2_LDS, st, p, s);
+  hipLaunchKernelGGL((gemm2_kernel<WM, NJ, A_KM, B_KM, GATHER, FP8, EPI>), dim3(grid), dim3(512), NJ == 8 ? 163840 : G2_LDS, st, p, s);
   MMSA_CHECK_LAUNCH();
   return MMSA_OK;
 }
 template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8 = false>
 static int g2_launch_t(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
   // plain-store and slab-store launches: the instantiation without the general epilogue (see gemm2_kernel)
-  if (s.fast || s.split_k > 1) return g2_launch_e<WM, NJ, A_KM, B_KM, GATHER, FP8, false>(p, s, grid, st);
-  return g2_launch_e<WM, NJ, A_KM, B_KM, GATHER, FP8, true>(p, s, grid, st);
+  if (s.fast || s.split_k > 1) return g2_launch_e<WM, NJ, A_KM, B_KM, GATHER, FP8, 0>(p, s, grid, st);
+  // the specialised epilogues exist for the plain (no gather, bf16 operands) NT and NN problems: the Linears of the text encoder
+  // and their data gradients, the 1x1 convolutions' data gradients with the skip connection's gradient added
+  if constexpr (!A_KM && GATHER == 0 && NJ != 8) {  // (fp8 operands: NT only, so kinds 2-4)
+    const int kind = g2_epi_kind(p);
+    if constexpr (!B_KM) {
+      if (kind == 2) return g2_launch_e<WM, NJ, A_KM, B_KM, GATHER, FP8, 2>(p, s, grid, st);
+      if (kind == 3) return g2_launch_e<WM, NJ, A_KM, B_KM, GATHER, FP8, 3>(p, s, grid, st);
+    } else {
+      if (kind == 5) return g2_launch_e<WM, NJ, A_KM, B_KM, GATHER, FP8, 5>(p, s, grid, st);
+    }
+    if (kind == 4) return g2_launch_e<WM, NJ, A_KM, B_KM, GATHER, FP8, 4>(p, s, grid, st);
+  }
+  return g2_launch_e<WM, NJ, A_KM, B_KM, GATHER, FP8, 1>(p, s, grid, st);
 }
 
 template <int WM, int NJ>
@@ -1496,7 +1545,7 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
     }
 #ifdef G2_ONLY_BIG  // build-time probe (-DG2_ONLY_BIG): the 256 x 256 variants alone, for a quick resource-usage report
 #ifdef G2_ONLY_NT44   // (+ the 256 x 128 NT kernel with the general epilogue)
-    else if (plan.nj == 4) rc = g2_launch_e<4, 4, false, false, 0, false, true>(p, s, grid, st);
+    else if (plan.nj == 4) rc = g2_launch_e<4, 4, false, false, 0, false, 1>(p, s, grid, st);
 #endif
     else rc = MMSA_ERR_UNSUPPORTED;
   } else rc = MMSA_ERR_UNSUPPORTED;

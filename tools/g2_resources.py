@@ -6,7 +6,7 @@ t = open(sys.argv[1]).read()
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 for b in re.split(r"remark: Function Name: ", t)[1:]:
     name = b.split(" ")[0]
-    m = re.match(r"_Z12gemm2_kernelILi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)E", name)
+    m = re.match(r"_Z12gemm2_kernelILi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d)ELb(\d)EL[bi](\d)E", name)
     if not m:
         continue
     key = ",".join(m.groups())
