@@ -268,7 +268,10 @@ __global__ __launch_bounds__(256, F32_WPS) void gemm_f32_mfma_kernel(GemmParams 
       img[((r & 3) + 8 * (r >> 2) + 4 * khalf) * 36 + (lane & 31)] = acc[bi][bj][r];
     __syncthreads();
     const int mb = m0 + wr * 64 + bi * 32, nb = n0 + wc * 64 + bj * 32;
+    // (both loops stay rolled: unrolled, the kernel carried 16 copies of the float4 epilogue and 64 of the scalar one —
+    //  115-159 KiB of code per instantiation against a 64 KiB instruction cache shared by the workgroups of two CUs)
     if (p.split_k > 1 || vec_ok) {
+#pragma unroll 1
       for (int i = 0; i < 4; ++i) {
         const int row = (lane >> 3) + 8 * i, c4 = (lane & 7) * 4;
         const int m = mb + row, n = nb + c4;
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(256, F32_WPS) void gemm_f32_mfma_kernel(GemmParams 
         }
       }
     } else {
+#pragma unroll 1
       for (int i = 0; i < 16; ++i) {
         const int row = (lane >> 5) + 2 * i, col = lane & 31;
         const int m = mb + row, n = nb + col;
