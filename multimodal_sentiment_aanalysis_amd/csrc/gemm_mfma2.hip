@@ -1482,10 +1482,11 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   s.rb = 0; s.cb = 0;
   s.fd_cb = make_fastdiv(1); s.fd_sbc = make_fastdiv(1);
   {
-    // Opt-in (MMSA_G2_2D=1): measured on MI355X it changes neither the stand-alone GEMM times nor the step (the CUs of
-    // an XCD walk K in lock-step, so whoever shares a panel waits for the same fill either way); it only lowers the
-    // L2-miss traffic that the Infinity Cache absorbs.
-    static const bool no2d = [] { const char* v = getenv("MMSA_G2_2D"); return !(v && atoi(v) != 0); }();
+    // On by default since round 3 (MMSA_G2_2D=0 turns it off): in round 2 it changed neither the stand-alone GEMM times nor the
+    // step (the CUs of an XCD walk K in lock-step, so whoever shares a panel waits for the same fill either way) and only lowered
+    // the L2-miss traffic the Infinity Cache absorbs; with the leaner round-3 kernels the same A/B reads 17.79-17.87 against
+    // 18.02-18.11 ms/step (GEMM time 10.15 against 10.36 ms).
+    static const bool no2d = [] { const char* v = getenv("MMSA_G2_2D"); return v && atoi(v) == 0; }();
     // 2-D blocking when it lowers (2 rb + cb): A panel = 32 KiB, B panel = 16 KiB per K step and XCD
     int best_cb = 0;
     double best = 2.0 * 32.0 / s.ntn + s.ntn;  // row-major: a run of 32 tiles spans 32/ntn rows and all ntn columns
