@@ -356,7 +356,7 @@ class FusedTrainStep:
     """model: MultimodalTransformerModel (Trainer contract). One call = one optimizer step."""
 
     def __init__(self, model, device, precision="bf16", lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
-                 max_norm=1.0, bucket_bytes=64 << 20, two_streams=False, min_bucket_bytes=16 << 20, train_mode=True):
+                 max_norm=1.0, bucket_bytes=64 << 20, two_streams=None, min_bucket_bytes=16 << 20, train_mode=True):
         """train_mode=False: the forward runs in eval mode (BatchNorm on its running statistics, no dropout) while gradients
         and the optimizer step are still taken — the configuration SURVEY.md section 8(e) prescribes for checking that N ranks x
         B/N samples reproduce one rank x B samples (batch statistics would differ between the two by construction)."""
@@ -383,9 +383,15 @@ class FusedTrainStep:
         if self.world > 1:  # identical replicas: parameters and BN buffers from rank 0
             dist.broadcast(self.state.flat_w, 0)
             dist.broadcast(self.state.flat_bn, 0)
-        # optional: the image encoder on its own HIP stream beside the text encoder (joined before the head / the
-        # optimizer). Measured on MI355X: a loss (19.50 vs 19.23 ms/step single-stream) — the persistent GEMM workgroups
-        # take the whole register file of their CU, so the two streams' kernels only stretch each other; off by default.
+        # The image encoder runs on its own HIP stream beside the text encoder (joined before the head / the optimizer): its
+        # many latency-bound kernels (BatchNorm finalizes, small-grid BatchNorm passes, slab reducers) fill the launch bubbles
+        # and tails of the text encoder's GEMMs and vice versa. Measured on MI355X, same box: 17.59-17.61 against 17.95-18.03
+        # ms/step (round 3). (In rounds 1-2 it was a loss, 19.50 vs 19.23: two persistent GEMMs that meet only stretch each
+        # other — the sum of the GEMM kernels' own durations still grows, 10.28 -> 10.98 ms — but the kernels around them got
+        # leaner since.) two_streams=None: on unless MMSA_TWO_STREAMS=0.
+        if two_streams is None:
+            two_streams = os.environ.get("MMSA_TWO_STREAMS", "1") != "0"
+        self.two_streams = bool(two_streams)
         self._image_net = getattr(getattr(model, "encoder", None), "image_net", None)
         if self._image_net is not None and self.device.type == "cuda" and two_streams:
             self._image_net.use_side_stream(True)

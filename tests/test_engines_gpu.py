@@ -726,6 +726,44 @@ def test_full_size_train_step_properties(dev, B):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (l1, l2)
 
 
+@pytest.mark.parametrize("full", [False, True])
+def test_image_encoder_on_its_own_stream_changes_nothing(dev, full):
+    """FusedTrainStep runs the image encoder on a side HIP stream beside the text encoder (two_streams, the default). The two
+    encoders touch disjoint gradient ranges, workspaces and statistics buffers and meet only at the fusion head and at the
+    optimizer, both behind event joins: losses, logits, every updated weight, both AdamW moments and the BatchNorm running
+    statistics must be BIT-identical to the single-stream run — any missing ordering edge shows up as a difference (the
+    word-embedding scatter's fp32 atomics are inside one encoder on one stream in both runs; a batch without repeated tokens
+    keeps even them exact). Mini configuration, and the benchmark's own model at B = 16."""
+    from multimodal_sentiment_aanalysis_amd.fused import FusedTrainStep
+    if full:
+        image, ids, mask, labels = synth_batch(16, 128, 224, 224, 30522, seed=5)
+        mk = lambda: mm.MultimodalTransformerModel(dropout=0.0)  # noqa: E731
+    else:
+        image, ids, mask, labels = synth_batch(8, 32, 64, 64, MINI_BERT["vocab"], seed=3)
+        mk = lambda: mm.MultimodalTransformerModel(bert_config=MINI_BERT, resnet_config=MINI_RESNET, dropout=0.0)  # noqa: E731
+    ids = torch.stack([torch.randperm(int(ids.max()) + 1, generator=torch.Generator().manual_seed(40 + r))[:ids.shape[1]]
+                       for r in range(ids.shape[0])]).to(ids.dtype)  # no token twice in a row: no atomic meets another
+    batch = (image.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
+
+    def run(two):
+        torch.manual_seed(0)
+        step = FusedTrainStep(mk(), dev, precision="bf16", lr=1e-3, two_streams=two)
+        assert step.two_streams == two and (getattr(step._image_net, "_side", None) is not None) == two
+        out = []
+        for _ in range(3):
+            loss, logits = step.step(*batch)
+            out.append((loss.clone(), logits.clone()))
+        torch.cuda.synchronize()
+        st = step.state
+        return out, st.flat_w.clone(), step.opt.m.clone(), step.opt.v.clone(), st.flat_bn.clone()
+
+    a, b = run(True), run(False)
+    for (la, ga), (lb, gb) in zip(a[0], b[0]):
+        assert torch.equal(la, lb) and torch.equal(ga, gb)
+    for x, y, what in zip(a[1:], b[1:], ("weights", "exp_avg", "exp_avg_sq", "BatchNorm buffers")):
+        assert torch.equal(x, y), f"{what} differ between the two-stream and the single-stream step"
+
+
 def test_c3_bert_large_resnet101_train_steps(dev):
     """BASELINE.json configs[3] (BERT-large S = 256 + ResNet-101): the largest configuration runs through the same engines
     (attention backward at S = 256: the recompute MFMA kernel) at its stated per-GPU batch of 32 — a fixed batch's loss is
