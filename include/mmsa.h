@@ -215,6 +215,14 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* c, const float* w32, const void* wt, c
                      int32_t layers_per_chunk, const uint8_t* frozen);
 int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* c, const float* w32, const void* wt, void* ws, const float* dfeat, float* grad,
                        int32_t accumulate, void* stream, mmsa_range_cb cb, void* user, const uint8_t* frozen);
+/* The same with an optional second stream of the same device for the weight gradients: the stage-wise grouped weight-gradient
+ * launches (mmsa_gemm_group_split's kernel) are enqueued on wgrad_stream, ordered after their stage's backward by an event and
+ * joined into `stream` by an event before the call returns, so these throughput-bound launches overlap the latency-bound
+ * BatchNorm / data-gradient chain of the following stages. Ignored (everything on `stream`) when cb is set or wgrad_stream is
+ * null. Results are bit-identical to mmsa_resnet_bwd_cb. */
+int mmsa_resnet_bwd_cb2(const mmsa_resnet_cfg* c, const float* w32, const void* wt, void* ws, const float* dfeat, float* grad,
+                        int32_t accumulate, void* stream, void* wgrad_stream, mmsa_range_cb cb, void* user,
+                        const uint8_t* frozen);
 /* `frozen` (host array, one byte per entry of the engine's parameter table, NULL = everything trainable): SURVEY.md §8f N2 — the
  * reference's curriculum phases (dataLoader/MultiTaskTrainer.py:50-177) and fine-tuning (train.py:90-92) freeze sub-graphs. A
  * wholly frozen group (BERT: embeddings / one encoder layer / pooler + projection; ResNet: stem / one bottleneck / projection)

@@ -97,7 +97,7 @@ struct ResWs {
   void* foldw;  // inference: one convolution's weights with its BatchNorm scale folded in (largest weight)
   void* dzarena;  // backward: the pre-BatchNorm gradients dz of one stage's convolutions, kept until the stage's weight gradients
   size_t dzarena_bytes;  // go out as grouped launches (Eng::wgrad_batch)
-  float *stem_dw, *splitk, *colws, *bnws;
+  float *stem_dw, *splitk, *splitk2, *colws, *bnws;  // splitk2: slabs of the weight-gradient groups when they run on their own stream
   long bnws_floats;  // capacity of the partial-sum part of bnws (conv-epilogue statistics: GemmParams::colstat_cap)
   size_t splitk_bytes;
   size_t total;
@@ -155,24 +155,28 @@ static ResWs res_ws(const mmsa_resnet_cfg& c, const ResLayout& L, void* base) {
   w.g2 = b.take(maxact * es);
   w.g3 = b.take(maxact * es);
   {
-    // largest per-stage sum of convolution outputs (a stage = the blocks down to and including one with a downsample branch)
-    size_t run = 0, best = 0;
+    // sum of the convolution outputs of the whole net (a stage's weight gradients may still be reading their dz slots on the
+    // weight-gradient stream while the next stage's backward fills its own: no slot is reused inside one backward; 1.4 GB of the
+    // 288 at B = 64). `run` / `best` = the largest stage: the flush threshold when everything runs on one stream.
+    size_t run = 0, best = 0, all = 0;
     for (int i = (int)L.blocks.size() - 1; i >= 0; --i) {
       const BlockDef& bd = L.blocks[i];
       const ConvDef* cs[4] = {&bd.c1, &bd.c2, &bd.c3, bd.has_ds ? &bd.ds : nullptr};
       for (const ConvDef* cd : cs)
-        if (cd) run += align_up((size_t)B * cd->Hout * cd->Wout * cd->Cout * es, 256);
+        if (cd) { run += align_up((size_t)B * cd->Hout * cd->Wout * cd->Cout * es, 256); all += align_up((size_t)B * cd->Hout * cd->Wout * cd->Cout * es, 256); }
       if (run > best) best = run;
       if (bd.has_ds) run = 0;
     }
-    w.dzarena_bytes = best;
-    w.dzarena = b.take(best);
+    (void)best;
+    w.dzarena_bytes = all;
+    w.dzarena = b.take(all);
   }
   w.stem_dw = (float*)b.take((size_t)64 * L.Kstem_pad * 4);
   w.foldw = b.take(maxw * es);
   // split-K slabs for the weight gradients: up to 64 slabs of the small early-stage weights, fewer of the large ones
   w.splitk_bytes = (size_t)16 * maxw * sizeof(float);
   w.splitk = (float*)b.take(w.splitk_bytes);
+  w.splitk2 = (float*)b.take(w.splitk_bytes);
   w.colws = (float*)b.take(colsum_ws_bytes(maxc > c.out_dim ? maxc : c.out_dim));
   w.bnws = (float*)b.take(bn_ws_bytes(maxc));
   w.bnws_floats = (long)(bn_ws_bytes(maxc) / sizeof(float)) - 2L * maxc;  // the partial-sum part (the tail holds the backward's sums)
@@ -503,7 +507,7 @@ int mmsa_resnet_fwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
 
 int mmsa_resnet_bwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt, void* ws_base, const float* dfeat, float* grad,
                     int32_t accumulate, void* stream) {
-  return mmsa_resnet_bwd_cb(cp, w32, wt, ws_base, dfeat, grad, accumulate, stream, nullptr, nullptr, nullptr);
+  return mmsa_resnet_bwd_cb2(cp, w32, wt, ws_base, dfeat, grad, accumulate, stream, nullptr, nullptr, nullptr, nullptr);
 }
 
 // The backward with a "gradient range ready" callback (see mmsa_bert_bwd_cb): the projection first, then one range per
@@ -511,6 +515,16 @@ int mmsa_resnet_bwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
 // the stem last.
 int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* wt, void* ws_base, const float* dfeat,
                        float* grad, int32_t accumulate, void* stream, mmsa_range_cb cb, void* user, const uint8_t* frozen) {
+  return mmsa_resnet_bwd_cb2(cp, w32, wt, ws_base, dfeat, grad, accumulate, stream, nullptr, cb, user, frozen);
+}
+
+// wgrad_stream (optional, another stream of the same device): the stage-wise weight-gradient groups are enqueued there —
+// ordered after the stage's backward by an event, joined into `stream` by an event before the call returns — so that these
+// throughput-bound launches overlap the latency-bound BatchNorm / data-gradient chain of the following stages. Without a range
+// callback only (a callback announces a stage's gradients as enqueued on `stream`).
+int mmsa_resnet_bwd_cb2(const mmsa_resnet_cfg* cp, const float* w32, const void* wt, void* ws_base, const float* dfeat,
+                        float* grad, int32_t accumulate, void* stream, void* wgrad_stream, mmsa_range_cb cb, void* user,
+                        const uint8_t* frozen) {
   if (!cp || !res_cfg_ok(*cp) || !w32 || !wt || !ws_base || !dfeat || !grad) return MMSA_ERR_ARG;
   const mmsa_resnet_cfg& c = *cp;
   const ResLayout L = res_layout(c);
@@ -562,11 +576,39 @@ int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* 
                      !(getenv("MMSA_NO_WGRAD_DEFER") && atoi(getenv("MMSA_NO_WGRAD_DEFER")) != 0);
   std::vector<GemmParams> pend;
   size_t arena_off = 0;
+  hipStream_t wst = (defer && !cb && wgrad_stream && wgrad_stream != stream) ? (hipStream_t)wgrad_stream : nullptr;
+  Eng ew = r.e;  // the engine view of the weight-gradient stream: its own stream and its own slab workspace
+  ew.st = wst;
+  ew.splitk_ws = ws.splitk2;
+  bool wst_used = false;
   auto flush = [&]() -> int {
-    const int rc = pend.empty() ? MMSA_OK : r.e.wgrad_batch(pend.data(), (int)pend.size());
+    int rc = MMSA_OK;
+    if (!pend.empty()) {
+      if (wst) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return MMSA_ERR_LAUNCH;
+        const bool ok = hipEventRecord(ev, st) == hipSuccess && hipStreamWaitEvent(wst, ev, 0) == hipSuccess;
+        (void)hipEventDestroy(ev);  // (released once the recorded work has completed)
+        if (!ok) return MMSA_ERR_LAUNCH;
+        for (GemmParams& q : pend) q.ws = ws.splitk2;
+        rc = ew.wgrad_batch(pend.data(), (int)pend.size());
+        wst_used = true;
+      } else {
+        rc = r.e.wgrad_batch(pend.data(), (int)pend.size());
+      }
+    }
     pend.clear();
-    arena_off = 0;
+    if (!wst) arena_off = 0;  // (with a weight-gradient stream no slot is reused: the arena spans the whole net)
     return rc;
+  };
+  auto join_wst = [&]() -> int {  // everything enqueued on the weight-gradient stream happens before what `stream` does next
+    if (!wst_used) return MMSA_OK;
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return MMSA_ERR_LAUNCH;
+    const bool ok = hipEventRecord(ev, wst) == hipSuccess && hipStreamWaitEvent(st, ev, 0) == hipSuccess;
+    (void)hipEventDestroy(ev);
+    wst_used = false;
+    return ok ? MMSA_OK : MMSA_ERR_LAUNCH;
   };
   // where the dz of convolution cd goes: its arena slot (deferred) or the ping-pong buffer `fallback`
   auto dz_slot = [&](const ConvDef& cd, void* fallback, bool wg, void** out) -> int {
@@ -608,7 +650,8 @@ int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* 
       if (atoi(dbg) == i) {
         if (dz1 != t1 && hipMemcpyAsync(t1, dz1, (size_t)B * bd.c1.Hout * bd.c1.Wout * bd.c1.Cout * r.es, hipMemcpyDeviceToDevice, st) != hipSuccess)
           return MMSA_ERR_LAUNCH;
-        return flush();
+        RET_IF(flush());
+        return join_wst();
       }
     }
     if (wg) RET_IF(wgrad(bd.c1, dz1, xin));
@@ -634,7 +677,7 @@ int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* 
     }
   }
   RET_IF(flush());
-  if (lowest >= 0) return MMSA_OK;  // the stem is frozen
+  if (lowest >= 0) return join_wst();  // the stem is frozen
   // max-pool, stem BN + ReLU, stem conv (weight gradient only: the image needs none)
   const ConvDef& s = L.stem;
   RET_IF(maxpool_bwd(c.dtype, dOut, ws.pool_idx, t1, B, s.Hout, s.Wout, 64, st));
@@ -650,7 +693,7 @@ int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* 
   }
   RET_IF(unpad_rows(ws.stem_dw, r.G(s.w), 64, L.Kstem_pad, 147, acc, st));
   if (cb) cb(user, 0, chunk_end);
-  return MMSA_OK;
+  return join_wst();
 }
 
 }  // extern "C"

@@ -248,6 +248,12 @@ class EngineModule(nn.Module):
                       and self._flat_w.is_cuda else None)
         self._pending = None
 
+    def use_wgrad_stream(self, on):
+        """Image encoder only: its backward enqueues the stage-wise weight-gradient groups on one more stream
+        (mmsa_resnet_bwd_cb2; ignored under data parallelism, where a stage's gradients are announced on the caller's stream)."""
+        self._wgrad_stream = (torch.cuda.Stream(device=self._flat_w.device) if on and self._flat_w is not None
+                              and self._flat_w.is_cuda else None)
+
     def _run_stream(self):
         """Context manager + stream the engine call goes to."""
         side = getattr(self, "_side", None)
@@ -458,9 +464,13 @@ class _ResnetFn(torch.autograd.Function):
         dfeat = dfeat.contiguous()
         side = eng._run_stream()
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            check(_lib.load().mmsa_resnet_bwd_cb(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ws),
-                                                 ptr(dfeat), ptr(eng._flat_g), eng._acc_flag(), stream_ptr(),
-                                                 eng._range_cb(), None, eng._frozen_mask()), "mmsa_resnet_bwd")
+            # the stage-wise weight-gradient groups on a stream of their own (EngineModule.use_wgrad_stream), beside the
+            # latency-bound BatchNorm / data-gradient chain of the following stages; joined before the call returns
+            wst = getattr(eng, "_wgrad_stream", None)
+            check(_lib.load().mmsa_resnet_bwd_cb2(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ws),
+                                                  ptr(dfeat), ptr(eng._flat_g), eng._acc_flag(), stream_ptr(),
+                                                  ctypes.c_void_p(wst.cuda_stream) if wst is not None else None,
+                                                  eng._range_cb(), None, eng._frozen_mask()), "mmsa_resnet_bwd")
             if side is not None:
                 dfeat.record_stream(side)
             eng._give_ws(ctx.ws)

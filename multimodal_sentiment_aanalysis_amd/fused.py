@@ -395,6 +395,10 @@ class FusedTrainStep:
         self._image_net = getattr(getattr(model, "encoder", None), "image_net", None)
         if self._image_net is not None and self.device.type == "cuda" and two_streams:
             self._image_net.use_side_stream(True)
+        # ... and its stage-wise weight-gradient groups on one more stream (mmsa_resnet_bwd_cb2): 17.15 against 17.37-17.46
+        # ms/step on the same box; MMSA_WGRAD_STREAM=0 turns it off; ignored by the engine under data parallelism
+        if self._image_net is not None and self.device.type == "cuda" and os.environ.get("MMSA_WGRAD_STREAM", "1") != "0":
+            self._image_net.use_wgrad_stream(True)
         # optional: the two cross-modal transformers on side streams beside the fusion chain (MMSA_HEAD_STREAMS=1; A/B hook)
         self._head_streams = None
         if os.environ.get("MMSA_HEAD_STREAMS", "0") == "1" and hasattr(model, "use_head_streams") and self.device.type == "cuda":

@@ -727,7 +727,7 @@ def test_full_size_train_step_properties(dev, B):
 
 
 @pytest.mark.parametrize("full", [False, True])
-def test_image_encoder_on_its_own_stream_changes_nothing(dev, full):
+def test_image_encoder_on_its_own_stream_changes_nothing(dev, monkeypatch, full):
     """FusedTrainStep runs the image encoder on a side HIP stream beside the text encoder (two_streams, the default). The two
     encoders touch disjoint gradient ranges, workspaces and statistics buffers and meet only at the fusion head and at the
     optimizer, both behind event joins: losses, logits, every updated weight, both AdamW moments and the BatchNorm running
@@ -745,10 +745,12 @@ def test_image_encoder_on_its_own_stream_changes_nothing(dev, full):
                        for r in range(ids.shape[0])]).to(ids.dtype)  # no token twice in a row: no atomic meets another
     batch = (image.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
 
-    def run(two):
+    def run(two, wgrad_stream=False):
+        monkeypatch.setenv("MMSA_WGRAD_STREAM", "1" if wgrad_stream else "0")
         torch.manual_seed(0)
         step = FusedTrainStep(mk(), dev, precision="bf16", lr=1e-3, two_streams=two)
         assert step.two_streams == two and (getattr(step._image_net, "_side", None) is not None) == two
+        assert (getattr(step._image_net, "_wgrad_stream", None) is not None) == wgrad_stream
         out = []
         for _ in range(3):
             loss, logits = step.step(*batch)
@@ -758,10 +760,13 @@ def test_image_encoder_on_its_own_stream_changes_nothing(dev, full):
         return out, st.flat_w.clone(), step.opt.m.clone(), step.opt.v.clone(), st.flat_bn.clone()
 
     a, b = run(True), run(False)
-    for (la, ga), (lb, gb) in zip(a[0], b[0]):
-        assert torch.equal(la, lb) and torch.equal(ga, gb)
-    for x, y, what in zip(a[1:], b[1:], ("weights", "exp_avg", "exp_avg_sq", "BatchNorm buffers")):
-        assert torch.equal(x, y), f"{what} differ between the two-stream and the single-stream step"
+    # ... and with the image encoder's stage-wise weight-gradient groups on a third stream (mmsa_resnet_bwd_cb2)
+    c = run(True, wgrad_stream=True)
+    for other, name in ((a, "two-stream"), (c, "three-stream")):
+        for (la, ga), (lb, gb) in zip(other[0], b[0]):
+            assert torch.equal(la, lb) and torch.equal(ga, gb), name
+        for x, y, what in zip(other[1:], b[1:], ("weights", "exp_avg", "exp_avg_sq", "BatchNorm buffers")):
+            assert torch.equal(x, y), f"{what} differ between the {name} and the single-stream step"
 
 
 def test_c3_bert_large_resnet101_train_steps(dev):
