@@ -301,6 +301,9 @@ def main(argv=None):
             img_net.join()
             sync()
             img_net.use_side_stream(False)
+            had_wgrad_stream = getattr(img_net, "_wgrad_stream", None) is not None
+            if had_wgrad_stream:
+                img_net.use_wgrad_stream(False)
             if dump:
                 os.environ["MMSA_PROF_DUMP"] = dump + ".isolated.csv"
             ms_i, fl_i, n_i = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
@@ -312,11 +315,13 @@ def main(argv=None):
             sync()
             L.mmsa_prof_end(ctypes.byref(ms_i), ctypes.byref(fl_i), ctypes.byref(n_i))
             img_net.use_side_stream(True)
+            if had_wgrad_stream:
+                img_net.use_wgrad_stream(True)
             if ms_i.value > 0:
                 tf_i = fl_i.value / (ms_i.value * 1e-3) / 1e12
                 isolated = {"achieved": round(tf_i, 2), "frac": round(tf_i / peak, 4),
                             "kernel_ms_per_step": round(ms_i.value / STAMP_STEPS, 3), "launches": n_i.value // STAMP_STEPS,
-                            "what": "the same launches with both encoders on one stream (MMSA_TWO_STREAMS=0): each kernel alone on the chip"}
+                            "what": "the same launches with everything on one stream (MMSA_TWO_STREAMS=0 MMSA_WGRAD_STREAM=0): each kernel alone on the chip"}
         if dump:
             os.environ["MMSA_PROF_DUMP"] = dump + ".fwd.csv"
         L.mmsa_prof_mode(0)
@@ -402,7 +407,8 @@ def main(argv=None):
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(alg_bytes_per_launch) if alg_bytes_per_launch else None,
-                         "streams": 2 if getattr(trainer, "two_streams", False) else 1,
+                         "streams": (1 + (1 if getattr(trainer, "two_streams", False) else 0)
+                                     + (1 if getattr(getattr(trainer, "_image_net", None), "_wgrad_stream", None) is not None else 0)),
                          "isolated": isolated,
                          "kernel": "every matrix-core GEMM launch (gemm2_kernel + split-K reducer; precision fp32: the "
                                    "fp32-MFMA kernel) of 3 steps right after the timed steps, averaged per step (NT/NN/TN, "
