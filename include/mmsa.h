@@ -213,6 +213,13 @@ typedef void (*mmsa_range_cb)(void* user, int64_t offset, int64_t length);
 int mmsa_bert_bwd_cb(const mmsa_bert_cfg* c, const float* w32, const void* wt, const int64_t* ids, const float* mask, void* ws,
                      const float* dfeat, float* grad, int32_t accumulate, void* stream, mmsa_range_cb cb, void* user,
                      int32_t layers_per_chunk, const uint8_t* frozen);
+/* The same with an optional second stream of the same device for the weight gradients (ignored when cb is set): every layer's
+ * grouped weight-gradient launch is enqueued on wgrad_stream after an event that follows its operands' producers, the layers
+ * alternate between two sets of gradient temporaries so that layer l's weight gradients overlap the backward chain of layer
+ * l - 1, and the stream is joined into `stream` before the call returns. Results are bit-identical to mmsa_bert_bwd_cb. */
+int mmsa_bert_bwd_cb2(const mmsa_bert_cfg* c, const float* w32, const void* wt, const int64_t* ids, const float* mask, void* ws,
+                      const float* dfeat, float* grad, int32_t accumulate, void* stream, void* wgrad_stream, mmsa_range_cb cb,
+                      void* user, int32_t layers_per_chunk, const uint8_t* frozen);
 int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* c, const float* w32, const void* wt, void* ws, const float* dfeat, float* grad,
                        int32_t accumulate, void* stream, mmsa_range_cb cb, void* user, const uint8_t* frozen);
 /* The same with an optional second stream of the same device for the weight gradients: the stage-wise grouped weight-gradient

@@ -78,6 +78,11 @@ struct BertWs {
   std::vector<BertLayerWs> L;
   void *pooled, *dfeat_t, *dpool, *dprepool;
   void *bufA, *bufB, *bufC, *bufD, *bufI, *bufQ;
+  // second set of the gradient temporaries a layer's weight gradients read (ds2, dpre, dqkv) and the two ds1 buffers: with the
+  // weight gradients on their own stream the NEXT layer's backward must not overwrite them (layers alternate between the sets)
+  void *bufB2, *bufI2, *bufQ2, *bufS[2];
+  float* colws2;  // the weight-gradient stream's own column-sum scratch
+  size_t colws2_bytes;
   void* ones8;  // [B*S][8] bf16 ones (grouped bias gradients, engine_common.h)
   void *q_act, *q_w;     // fp8 mode: e4m3 copy of a Linear's input ([B*S][max(H, I)]); e4m3 image of the whole weight table
                          // (byte i = element i of the bf16 working copy; only the quantized Linears' ranges are written)
@@ -123,12 +128,19 @@ static BertWs bert_ws(const mmsa_bert_cfg& c, void* base) {
   w.bufD = b.take(M * H * es);
   w.bufI = b.take(M * I * es);
   w.bufQ = b.take(M * 3 * H * es);
+  w.bufB2 = b.take(M * H * es);
+  w.bufI2 = b.take(M * I * es);
+  w.bufQ2 = b.take(M * 3 * H * es);
+  w.bufS[0] = b.take(M * H * es);
+  w.bufS[1] = b.take(M * H * es);
   // split-K slabs: the largest weight gradient is [I][H]; allow up to 8 slabs of it (pick_split respects the size)
   w.splitk_bytes = (size_t)8 * I * H * sizeof(float);
   w.splitk = (float*)b.take(w.splitk_bytes);
   size_t colb = colsum_ws_bytes((int)(3 * H > I ? 3 * H : I));
   w.colws = (float*)b.take(colb);
   w.colws_bytes = colb;
+  w.colws2 = (float*)b.take(colb);
+  w.colws2_bytes = colb;
   w.ones8 = b.take(M * 8 * 2);
   w.q_act = w.q_w = nullptr; w.q_wscales = w.q_rowscales = w.q_batchws = nullptr;
   if (c.dtype == MMSA_FP8) {
@@ -251,7 +263,7 @@ int mmsa_bert_fwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
 
 int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, const int64_t* ids, const float* mask,
                   void* ws_base, const float* dfeat, float* grad, int32_t accumulate, void* stream) {
-  return mmsa_bert_bwd_cb(cp, w32, wt, ids, mask, ws_base, dfeat, grad, accumulate, stream, nullptr, nullptr, 0, nullptr);
+  return mmsa_bert_bwd_cb2(cp, w32, wt, ids, mask, ws_base, dfeat, grad, accumulate, stream, nullptr, nullptr, nullptr, 0, nullptr);
 }
 
 // The backward with a "gradient range ready" callback: cb(user, offset, length) is called — on the host, from inside this
@@ -262,6 +274,16 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
 int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, const int64_t* ids, const float* mask,
                      void* ws_base, const float* dfeat, float* grad, int32_t accumulate, void* stream, mmsa_range_cb cb,
                      void* user, int32_t layers_per_chunk, const uint8_t* frozen) {
+  return mmsa_bert_bwd_cb2(cp, w32, wt, ids, mask, ws_base, dfeat, grad, accumulate, stream, nullptr, cb, user, layers_per_chunk, frozen);
+}
+
+// wgrad_stream (optional, another stream of the same device; ignored when cb is set): every layer's grouped weight-gradient
+// launch is enqueued there — after an event that follows the kernels producing its operands — and the layers alternate between
+// two sets of gradient temporaries, so layer l's weight gradients overlap the backward chain of layer l - 1; the stream is
+// joined into `stream` before the call returns. Bit-identical to mmsa_bert_bwd_cb.
+int mmsa_bert_bwd_cb2(const mmsa_bert_cfg* cp, const float* w32, const void* wt, const int64_t* ids, const float* mask,
+                      void* ws_base, const float* dfeat, float* grad, int32_t accumulate, void* stream, void* wgrad_stream,
+                      mmsa_range_cb cb, void* user, int32_t layers_per_chunk, const uint8_t* frozen) {
   if (!cp || !bert_cfg_ok(*cp) || !w32 || !wt || !ids || !ws_base || !dfeat || !grad) return MMSA_ERR_ARG;
   if (layers_per_chunk < 1) layers_per_chunk = 1;
   const mmsa_bert_cfg& c = *cp;
@@ -316,7 +338,17 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
     if (cb) cb(user, lay.wp, lay.t.total - lay.wp);
   }
   if (lowest == nl) return MMSA_OK;  // every encoder layer and the embeddings are frozen: the backward ends here
-  void *dOut = ws.bufA, *bB = ws.bufB, *bC = ws.bufC;
+  void *dOut = ws.bufA, *bC = ws.bufC;
+  void* setB[2] = {ws.bufB, ws.bufB2};
+  void* setI[2] = {ws.bufI, ws.bufI2};
+  void* setQ[2] = {ws.bufQ, ws.bufQ2};
+  hipStream_t wst = (!cb && wgrad_stream && wgrad_stream != stream && sdt(c) == MMSA_BF16 && !Eng::force_simt()) ? (hipStream_t)wgrad_stream : nullptr;
+  Eng ew = e;  // the engine view of the weight-gradient stream: its own stream and column-sum scratch
+  ew.st = wst;
+  ew.col_ws = ws.colws2;
+  ew.col_ws_bytes = ws.colws2_bytes;
+  hipEvent_t set_free[2] = {nullptr, nullptr};  // recorded on wst after the weight gradients that read set p
+  auto drop_events = [&]() { for (hipEvent_t& ev : set_free) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; } };
   if (hipMemsetAsync(dOut, 0, (size_t)M * H * es, st) != hipSuccess) return MMSA_ERR_LAUNCH;
   RET_IF(e.linear_dgrad(ws.dprepool, H, W(lay.wp), dOut, (long)S * H, B, H, H));  // only the [CLS] rows receive gradient
   long chunk_end = lay.wp;  // encoder layers [l, ...) up to chunk_end are complete but not yet announced
@@ -327,24 +359,30 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
     BertLayerWs& a = ws.L[l];
     const void* xin = l == 0 ? ws.x0 : ws.L[l - 1].out;
     const bool last_needed = (l == lowest);  // nothing trainable below: this layer's input needs no gradient
-    void* ds2 = bB;
+    const int par = wst ? ((c.layers - 1 - l) & 1) : 0;  // which set of gradient temporaries this layer writes
+    if (wst && set_free[par]) {  // the weight gradients of layer l + 2 read this set: they must be done before it is rewritten
+      if (hipStreamWaitEvent(st, set_free[par], 0) != hipSuccess) { drop_events(); return MMSA_ERR_LAUNCH; }
+      (void)hipEventDestroy(set_free[par]);
+      set_free[par] = nullptr;
+    }
+    void* ds2 = setB[par];
     // ds2 is also dY of the FFN output Linear: its bias gradient (column sums of ds2) comes out of the same pass
     // (a wholly frozen layer produces NO parameter gradient: its LayerNorm / bias gradient outputs are null, so that stale
     //  gradients of an earlier phase stay what torch would keep and a data-parallel replica never steps an un-reduced range)
     const bool lf = layer_frozen[l];
     RET_IF(layernorm_bwd(sdt(c), dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, lf ? nullptr : G(f.ln2w),
                          lf ? nullptr : G(f.ln2b), acc, ws.lnws, M, H, st, lf ? nullptr : G(f.b2)));
-    void* dpre = ws.bufI;
+    void* dpre = setI[par];
     RET_IF(e.linear_dgrad(ds2, H, W(f.w2), dpre, I, M, H, I, a.pre, I, nullptr, 0, gelu_factor()));  // * gelu'(pre), stored by the forward
     void* dh1 = bC;
     RET_IF(e.linear_dgrad(dpre, I, W(f.w1), dh1, H, M, I, H, nullptr, 0, ds2, H));  // + residual branch
-    void* ds1 = dOut;
+    void* ds1 = ws.bufS[par];  // (its own buffer: dOut / bC rotate under it while the weight gradients still read it)
     RET_IF(layernorm_bwd(sdt(c), dh1, a.s1, a.mean1, a.rstd1, P(f.ln1w), ds1, lf ? nullptr : G(f.ln1w),
                          lf ? nullptr : G(f.ln1b), acc, ws.lnws, M, H, st,
                          lf ? nullptr : G(f.bo)));  // + bias gradient of the attention output Linear
     void* dctx = ws.bufD;
     RET_IF(e.linear_dgrad(ds1, H, W(f.wo), dctx, H, M, H, H));
-    void* dqkv = ws.bufQ;
+    void* dqkv = setQ[par];
     RET_IF(attention_bwd(aimpl, a.qkv, mask, dctx, dqkv, ws.attnws, B, S, c.heads, 64, st));
     void* dx = bC;
     if (!last_needed)
@@ -359,7 +397,19 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
           {ds1, H, a.ctx, H, G(f.wo), nullptr, H, H},
           {dqkv, 3L * H, xin, H, G(f.wqkv), G(f.bqkv), 3 * H, H},
       };
-      RET_IF(e.wgrad_group(jobs, 4, M, acc));
+      if (wst) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { drop_events(); return MMSA_ERR_LAUNCH; }
+        const bool ok = hipEventRecord(ev, st) == hipSuccess && hipStreamWaitEvent(wst, ev, 0) == hipSuccess;
+        (void)hipEventDestroy(ev);
+        if (!ok) { drop_events(); return MMSA_ERR_LAUNCH; }
+        const int rc = ew.wgrad_group(jobs, 4, M, acc);
+        if (rc) { drop_events(); return rc; }
+        if (hipEventCreateWithFlags(&set_free[par], hipEventDisableTiming) != hipSuccess ||
+            hipEventRecord(set_free[par], wst) != hipSuccess) { drop_events(); return MMSA_ERR_LAUNCH; }
+      } else {
+        RET_IF(e.wgrad_group(jobs, 4, M, acc));
+      }
     }
     // rotate: dx becomes the next layer's dOut
     void* t = dOut; dOut = bC; bC = t;
@@ -369,9 +419,18 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
       chunk_live = false;
     }
   }
+  // everything on the weight-gradient stream happens before what `stream` does after this call (and before the embedding
+  // backward below reuses the first set's buffer)
+  for (int p = 0; p < 2; ++p)
+    if (set_free[p]) {
+      const bool ok = hipStreamWaitEvent(st, set_free[p], 0) == hipSuccess;
+      (void)hipEventDestroy(set_free[p]);
+      set_free[p] = nullptr;
+      if (!ok) { drop_events(); return MMSA_ERR_LAUNCH; }
+    }
   if (lowest >= 0) return MMSA_OK;  // the embeddings are frozen
   // embeddings
-  void* de = bB;
+  void* de = ws.bufB;
   RET_IF(layernorm_bwd(sdt(c), dOut, ws.e, ws.mean0, ws.rstd0, P(lay.lnw), de, G(lay.lnw), G(lay.lnb), acc, ws.lnws, M, H, st));
   if (!acc && c.type_vocab > 1 &&
       hipMemsetAsync(G(lay.type) + H, 0, (size_t)(c.type_vocab - 1) * H * sizeof(float), st) != hipSuccess)

@@ -249,8 +249,9 @@ class EngineModule(nn.Module):
         self._pending = None
 
     def use_wgrad_stream(self, on):
-        """Image encoder only: its backward enqueues the stage-wise weight-gradient groups on one more stream
-        (mmsa_resnet_bwd_cb2; ignored under data parallelism, where a stage's gradients are announced on the caller's stream)."""
+        """The encoder's backward enqueues its weight-gradient groups (per ResNet stage / per BERT layer) on one more stream
+        (mmsa_resnet_bwd_cb2 / mmsa_bert_bwd_cb2; ignored under data parallelism, where gradients are announced on the
+        caller's stream)."""
         self._wgrad_stream = (torch.cuda.Stream(device=self._flat_w.device) if on and self._flat_w is not None
                               and self._flat_w.is_cuda else None)
 
@@ -369,10 +370,12 @@ class _BertFn(torch.autograd.Function):
     def backward(ctx, dfeat):
         eng = ctx.eng
         eng._ensure_grads()
-        check(_lib.load().mmsa_bert_bwd_cb(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ids),
-                                           ptr(ctx.mask), ptr(ctx.ws), ptr(dfeat.contiguous()), ptr(eng._flat_g),
-                                           eng._acc_flag(), stream_ptr(), eng._range_cb(), None,
-                                           int(getattr(eng, "layers_per_chunk", 3)), eng._frozen_mask()), "mmsa_bert_bwd")
+        wst = getattr(eng, "_wgrad_stream", None)  # the layers' weight-gradient groups on a stream of their own (use_wgrad_stream)
+        check(_lib.load().mmsa_bert_bwd_cb2(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ids),
+                                            ptr(ctx.mask), ptr(ctx.ws), ptr(dfeat.contiguous()), ptr(eng._flat_g),
+                                            eng._acc_flag(), stream_ptr(),
+                                            ctypes.c_void_p(wst.cuda_stream) if wst is not None else None, eng._range_cb(), None,
+                                            int(getattr(eng, "layers_per_chunk", 3)), eng._frozen_mask()), "mmsa_bert_bwd")
         eng._give_ws(ctx.ws)
         ctx.ws = None
         if getattr(eng, "_grad_ready_hook", None) is not None:

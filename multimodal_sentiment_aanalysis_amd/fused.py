@@ -399,6 +399,10 @@ class FusedTrainStep:
         # ms/step on the same box; MMSA_WGRAD_STREAM=0 turns it off; ignored by the engine under data parallelism
         if self._image_net is not None and self.device.type == "cuda" and os.environ.get("MMSA_WGRAD_STREAM", "1") != "0":
             self._image_net.use_wgrad_stream(True)
+        # experiment: the text encoder's per-layer weight-gradient groups on a stream of their own as well (mmsa_bert_bwd_cb2)
+        self._text_net = getattr(getattr(model, "encoder", None), "text_net", None)
+        if self._text_net is not None and self.device.type == "cuda" and os.environ.get("MMSA_BERT_WGRAD_STREAM", "0") == "1":
+            self._text_net.use_wgrad_stream(True)
         # optional: the two cross-modal transformers on side streams beside the fusion chain (MMSA_HEAD_STREAMS=1; A/B hook)
         self._head_streams = None
         if os.environ.get("MMSA_HEAD_STREAMS", "0") == "1" and hasattr(model, "use_head_streams") and self.device.type == "cuda":

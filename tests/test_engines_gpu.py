@@ -745,8 +745,9 @@ def test_image_encoder_on_its_own_stream_changes_nothing(dev, monkeypatch, full)
                        for r in range(ids.shape[0])]).to(ids.dtype)  # no token twice in a row: no atomic meets another
     batch = (image.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
 
-    def run(two, wgrad_stream=False):
+    def run(two, wgrad_stream=False, bert_wgrad_stream=False):
         monkeypatch.setenv("MMSA_WGRAD_STREAM", "1" if wgrad_stream else "0")
+        monkeypatch.setenv("MMSA_BERT_WGRAD_STREAM", "1" if bert_wgrad_stream else "0")
         torch.manual_seed(0)
         step = FusedTrainStep(mk(), dev, precision="bf16", lr=1e-3, two_streams=two)
         assert step.two_streams == two and (getattr(step._image_net, "_side", None) is not None) == two
@@ -762,7 +763,10 @@ def test_image_encoder_on_its_own_stream_changes_nothing(dev, monkeypatch, full)
     a, b = run(True), run(False)
     # ... and with the image encoder's stage-wise weight-gradient groups on a third stream (mmsa_resnet_bwd_cb2)
     c = run(True, wgrad_stream=True)
-    for other, name in ((a, "two-stream"), (c, "three-stream")):
+    # ... and with the text encoder's per-layer weight-gradient groups on a stream of their own too (mmsa_bert_bwd_cb2:
+    # alternating sets of gradient temporaries, event-ordered reuse)
+    d = run(True, wgrad_stream=True, bert_wgrad_stream=True)
+    for other, name in ((a, "two-stream"), (c, "three-stream"), (d, "four-stream")):
         for (la, ga), (lb, gb) in zip(other[0], b[0]):
             assert torch.equal(la, lb) and torch.equal(ga, gb), name
         for x, y, what in zip(other[1:], b[1:], ("weights", "exp_avg", "exp_avg_sq", "BatchNorm buffers")):
