@@ -109,7 +109,7 @@ __host__ __device__ __forceinline__ long b_tap_offset(const GemmParams& p, int k
 int gemm_bf16_launch(const GemmParams& p, hipStream_t st);
 bool gemm2_eligible(const GemmParams& p);
 int gemm2_launch(const GemmParams& p, size_t ws_bytes_avail, hipStream_t st);
-extern int g2_last_plan[3];
+extern thread_local int g2_last_plan[3];  // (thread_local: the two encoders may be enqueued from two host threads)
 #define GEMM_MAX_GROUPS 12  // problems of one grouped weight-gradient launch
 int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st);
 int gemm_bf16_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st);  // + roofline record

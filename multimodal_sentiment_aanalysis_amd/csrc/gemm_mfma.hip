@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <mutex>
 #include <vector>
 #include "gemm.h"
 #include "gemm_epilogue.h"
@@ -398,6 +399,7 @@ static int g_prof_mode = 0;  // 0: HIP events around each launch; 1: in-kernel c
 static std::vector<ProfRec> g_prof;
 static size_t g_prof_used = 0;
 static bool g_prof_on = false;
+static std::recursive_mutex g_prof_mu;  // profiled launches are serialised (the encoders may be enqueued from two host threads)
 static int g_prof_stride = 1, g_prof_phase = 0;
 static long g_prof_index = 0;  // running launch index since the last gemm_prof_sample()
 
@@ -490,6 +492,8 @@ int gemm_prof_end(double* total_ms, double* total_flop, long* launches) {
 static int gemm_bf16_launch_inner(const GemmParams& pin, hipStream_t st);
 
 int gemm_prof_open(GemmParams& p, hipStream_t st) {
+  if (!g_prof_on) return -1;
+  std::lock_guard<std::recursive_mutex> lock(g_prof_mu);
   if (!g_prof_on || g_prof_used >= g_prof.size() || !prof_take()) return -1;
   const int slot = (int)g_prof_used++;
   ProfRec& r = g_prof[slot];
@@ -509,6 +513,8 @@ void gemm_prof_close(int slot, hipStream_t st) {
 int gemm_bf16_launch(const GemmParams& pin, hipStream_t st) {
   // batch-row problems: latency, not throughput (gemm_f32_tiny.hip); not part of the MFMA roofline record set
   if (gemm_bf16_tiny_eligible(pin)) return gemm_bf16_tiny_launch(pin, st);
+  if (!g_prof_on) return gemm_bf16_launch_inner(pin, st);
+  std::lock_guard<std::recursive_mutex> lock(g_prof_mu);
   if (!g_prof_on || g_prof_used >= g_prof.size() || !prof_take()) return gemm_bf16_launch_inner(pin, st);
   ProfRec& r = g_prof[g_prof_used];
   r.flop = 2.0 * pin.M * pin.N * (double)pin.K;
@@ -537,6 +543,8 @@ int gemm_bf16_launch_group(const GemmParams* probs, float* const* colsum, int n,
   static const bool v1_only = [] { const char* v = getenv("MMSA_GEMM_V1"); return v && atoi(v) != 0; }();
   static const bool no_group = [] { const char* v = getenv("MMSA_G2_NOGROUP"); return v && atoi(v) != 0; }();
   if (v1_only || no_group || use_regstage()) return MMSA_ERR_UNSUPPORTED;
+  if (!g_prof_on) return gemm2_launch_group(probs, colsum, n, st);
+  std::lock_guard<std::recursive_mutex> lock(g_prof_mu);
   if (!g_prof_on || g_prof_used >= g_prof.size() || !prof_take()) return gemm2_launch_group(probs, colsum, n, st);
   ProfRec& r = g_prof[g_prof_used];
   r.flop = 0;

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <mutex>
 #include <vector>
 #include "gemm.h"
 #include "gemm_epilogue.h"
@@ -1267,7 +1268,7 @@ bool gemm2_eligible(const GemmParams& p) {
   return true;
 }
 
-int g2_last_plan[3] = {0, 0, 0};  // profiling only (gemm_mfma.hip): tile shape and K split of the latest launch
+thread_local int g2_last_plan[3] = {0, 0, 0};  // profiling only (gemm_mfma.hip): tile shape and K split of the latest launch
 
 static inline int g2_epi_class(const GemmParams& p) {
   return (p.mul || p.add) ? 2 : (p.bias || p.C2 || p.act != MMSA_ACT_NONE || (p.out_f32 && p.accumulate)) ? 1 : 0;
@@ -1389,6 +1390,8 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
 static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
   struct Key { int M, N, K, epi, big_ok; size_t ws; G2Plan plan; };  // (epi: class * 8 + kind)
   static std::vector<Key> cache;
+  static std::mutex mu;  // the two encoders may be enqueued from two host threads (engine.py: EngineModule.use_host_worker)
+  std::lock_guard<std::mutex> lock(mu);
   const int epi = g2_epi_class(p) * 8 + (g2_epi_class(p) ? g2_epi_kind(p) : 0);
   const int big_ok = !(p.gather || p.scale_a || p.c_gw > 0 || p.colstat || p.mul || p.add || p.a_kmajor);  // which tile shapes exist
   for (const Key& k : cache)

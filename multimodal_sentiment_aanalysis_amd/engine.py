@@ -261,8 +261,8 @@ class EngineModule(nn.Module):
         if side is None:
             return None
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(side.device))
-        side.wait_event(ev)
+        ev.record(torch.cuda.current_stream(side.device))  # (in the caller's thread: current_stream is thread-local)
+        side.wait_event(ev)  # (host-side enqueue of a wait: safe from any thread)
         return side
 
     def _mark_pending(self, side):
@@ -270,7 +270,35 @@ class EngineModule(nn.Module):
         ev.record(side)
         self._pending = ev
 
+    def use_host_worker(self, on):
+        """With a side stream: the engine's C calls (each enqueues a few hundred kernels: 4-5 ms of host time) run on a worker
+        thread of their own, so the host enqueues both encoders at the same time (ctypes releases the GIL) — the two streams then
+        really have work from the start instead of one encoder's kernels arriving while the other's are half done. `join()`
+        waits for the worker before it joins the stream. Single-process only (a data-parallel step announces gradient ranges
+        from inside the call)."""
+        import concurrent.futures
+        old = getattr(self, "_worker", None)
+        if old is not None:
+            old.shutdown(wait=True)
+        self._worker = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="mmsa-enqueue") if on else None
+        self._inflight = None
+
+    def _submit(self, fn):
+        """Run fn (the stream-scoped engine call) on the worker thread if there is one, else inline."""
+        worker = getattr(self, "_worker", None)
+        if worker is None or getattr(self, "_side", None) is None:
+            fn()
+            return
+        prev = getattr(self, "_inflight", None)
+        if prev is not None:
+            prev.result()  # calls of one engine stay in order (and an exception of the previous one surfaces here)
+        self._inflight = worker.submit(fn)
+
     def join(self):
+        fut = getattr(self, "_inflight", None)
+        if fut is not None:
+            self._inflight = None
+            fut.result()
         ev = getattr(self, "_pending", None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
@@ -440,20 +468,25 @@ class _ResnetFn(torch.autograd.Function):
         nbytes = L.mmsa_resnet_ws_bytes(ctypes.byref(cfg))
         if nbytes == 0 or C != 3:
             raise MmsaError(f"unsupported ResNet input {tuple(image.shape)}")
-        side = eng._run_stream()
-        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            ws = eng._take_ws(nbytes, image.device)
-            feat = torch.empty(B, eng.out_dim, dtype=torch.float32, device=image.device)
-            wt = eng._sync_wt()
-            check(L.mmsa_resnet_fwd(ctypes.byref(cfg), ptr(eng._flat_w), ptr(wt), ptr(eng._flat_bn), ptr(image), ptr(ws),
-                                    ptr(feat), stream_ptr()), "mmsa_resnet_fwd")
-            if eng.training:
-                eng._flat_nbt.add_(1)
-            if side is not None:
-                image.record_stream(side)
-                eng._mark_pending(side)
-        if side is not None:  # produced on the side stream, consumed on the caller's
-            feat.record_stream(torch.cuda.current_stream(image.device))
+        ws = eng._take_ws(nbytes, image.device)
+        feat = torch.empty(B, eng.out_dim, dtype=torch.float32, device=image.device)
+        wt = eng._sync_wt()
+        training = eng.training
+        side = eng._run_stream()  # (after _sync_wt: a refresh of the working copy is enqueued on the caller's stream)
+
+        def enqueue():
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                check(L.mmsa_resnet_fwd(ctypes.byref(cfg), ptr(eng._flat_w), ptr(wt), ptr(eng._flat_bn), ptr(image), ptr(ws),
+                                        ptr(feat), stream_ptr()), "mmsa_resnet_fwd")
+                if training:
+                    eng._flat_nbt.add_(1)
+                if side is not None:
+                    eng._mark_pending(side)
+
+        if side is not None:  # allocated on the caller's stream, used on the side stream
+            for t in (image, feat, ws):
+                t.record_stream(side)
+        eng._submit(enqueue)
         if dummy is None:
             eng._give_ws(ws)
         else:
@@ -466,22 +499,28 @@ class _ResnetFn(torch.autograd.Function):
         eng._ensure_grads()
         dfeat = dfeat.contiguous()
         side = eng._run_stream()
-        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            # the stage-wise weight-gradient groups on a stream of their own (EngineModule.use_wgrad_stream), beside the
-            # latency-bound BatchNorm / data-gradient chain of the following stages; joined before the call returns
-            wst = getattr(eng, "_wgrad_stream", None)
-            check(_lib.load().mmsa_resnet_bwd_cb2(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ws),
-                                                  ptr(dfeat), ptr(eng._flat_g), eng._acc_flag(), stream_ptr(),
-                                                  ctypes.c_void_p(wst.cuda_stream) if wst is not None else None,
-                                                  eng._range_cb(), None, eng._frozen_mask()), "mmsa_resnet_bwd")
-            if side is not None:
-                dfeat.record_stream(side)
-            eng._give_ws(ctx.ws)
-            ctx.ws = None
-            if getattr(eng, "_grad_ready_hook", None) is not None:
-                eng._grad_ready_hook(eng)  # records its event on the stream the gradients are produced on
-            if side is not None:
-                eng._mark_pending(side)
+        cfg, ws, wt = ctx.cfg, ctx.ws, ctx.wt
+        ctx.ws = None
+        acc_flag, cb, frozen = eng._acc_flag(), eng._range_cb(), eng._frozen_mask()
+        if side is not None:
+            dfeat.record_stream(side)
+
+        def enqueue():
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                # the stage-wise weight-gradient groups on a stream of their own (EngineModule.use_wgrad_stream), beside the
+                # latency-bound BatchNorm / data-gradient chain of the following stages; joined before the call returns
+                wst = getattr(eng, "_wgrad_stream", None)
+                check(_lib.load().mmsa_resnet_bwd_cb2(ctypes.byref(cfg), ptr(eng._flat_w), ptr(wt), ptr(ws),
+                                                      ptr(dfeat), ptr(eng._flat_g), acc_flag, stream_ptr(),
+                                                      ctypes.c_void_p(wst.cuda_stream) if wst is not None else None,
+                                                      cb, None, frozen), "mmsa_resnet_bwd")
+                eng._give_ws(ws)
+                if getattr(eng, "_grad_ready_hook", None) is not None:
+                    eng._grad_ready_hook(eng)  # records its event on the stream the gradients are produced on
+                if side is not None:
+                    eng._mark_pending(side)
+
+        eng._submit(enqueue)
         return None, None, None
 
 

@@ -399,6 +399,11 @@ class FusedTrainStep:
         # ms/step on the same box; MMSA_WGRAD_STREAM=0 turns it off; ignored by the engine under data parallelism
         if self._image_net is not None and self.device.type == "cuda" and os.environ.get("MMSA_WGRAD_STREAM", "1") != "0":
             self._image_net.use_wgrad_stream(True)
+        # ... and its C calls on a host thread of their own (EngineModule.use_host_worker): both encoders are enqueued at the same
+        # time. Single process only. MMSA_HOST_WORKER=1 (experiment).
+        if (self._image_net is not None and self.device.type == "cuda" and two_streams and self.world == 1
+                and os.environ.get("MMSA_HOST_WORKER", "0") == "1"):
+            self._image_net.use_host_worker(True)
         # experiment: the text encoder's per-layer weight-gradient groups on a stream of their own as well (mmsa_bert_bwd_cb2)
         self._text_net = getattr(getattr(model, "encoder", None), "text_net", None)
         if self._text_net is not None and self.device.type == "cuda" and os.environ.get("MMSA_BERT_WGRAD_STREAM", "0") == "1":

@@ -745,7 +745,8 @@ def test_image_encoder_on_its_own_stream_changes_nothing(dev, monkeypatch, full)
                        for r in range(ids.shape[0])]).to(ids.dtype)  # no token twice in a row: no atomic meets another
     batch = (image.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
 
-    def run(two, wgrad_stream=False, bert_wgrad_stream=False):
+    def run(two, wgrad_stream=False, bert_wgrad_stream=False, host_worker=False):
+        monkeypatch.setenv("MMSA_HOST_WORKER", "1" if host_worker else "0")
         monkeypatch.setenv("MMSA_WGRAD_STREAM", "1" if wgrad_stream else "0")
         monkeypatch.setenv("MMSA_BERT_WGRAD_STREAM", "1" if bert_wgrad_stream else "0")
         torch.manual_seed(0)
@@ -766,7 +767,9 @@ def test_image_encoder_on_its_own_stream_changes_nothing(dev, monkeypatch, full)
     # ... and with the text encoder's per-layer weight-gradient groups on a stream of their own too (mmsa_bert_bwd_cb2:
     # alternating sets of gradient temporaries, event-ordered reuse)
     d = run(True, wgrad_stream=True, bert_wgrad_stream=True)
-    for other, name in ((a, "two-stream"), (c, "three-stream"), (d, "four-stream")):
+    # ... and with the image encoder's C calls enqueued from a host thread of their own (EngineModule.use_host_worker)
+    e = run(True, wgrad_stream=True, host_worker=True)
+    for other, name in ((a, "two-stream"), (c, "three-stream"), (d, "four-stream"), (e, "host-worker")):
         for (la, ga), (lb, gb) in zip(other[0], b[0]):
             assert torch.equal(la, lb) and torch.equal(ga, gb), name
         for x, y, what in zip(other[1:], b[1:], ("weights", "exp_avg", "exp_avg_sq", "BatchNorm buffers")):
