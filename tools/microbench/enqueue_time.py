@@ -20,3 +20,13 @@ for rep in range(3):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"host enqueue {1e3 * (t1 - t0) / n:.2f} ms/step; until the GPU is done {1e3 * (t2 - t0) / n:.2f} ms/step; GPU backlog at the end of the loop {1e3 * (t2 - t1):.1f} ms")
+# the loop above is throttled by back-pressure once the HIP queue is full (the host runs ~3 steps ahead and then waits for the
+# GPU): the UNTHROTTLED cost of enqueueing one step is measured from an empty queue
+ts = []
+for _ in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step.step(*batch)
+    ts.append(1e3 * (time.perf_counter() - t0))
+    torch.cuda.synchronize()
+print("host enqueue of one step from an empty queue:", " ".join(f"{t:.2f}" for t in ts), "ms")
