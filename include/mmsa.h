@@ -9,8 +9,11 @@
  *
  * Conventions
  *  - plain pointers to DEVICE memory + sizes; no torch types; `stream` is a hipStream_t passed as void*.
- *  - every call only enqueues work on `stream`: no allocation, no synchronization, no host copies
- *    (hipGraph-capturable). Scratch memory is caller-provided (`ws`), sized by the matching *_ws_bytes().
+ *  - every call only enqueues work on `stream`: no allocation, no synchronization, no host copies. A call that takes ONE stream
+ *    is hipGraph-capturable (tools/microbench/graph_probe.py replays the whole single-stream training step from a graph);
+ *    mmsa_resnet_bwd_cb2 with a second stream forks and joins it with events inside the call, and the Python step that drives
+ *    the encoders on three streams is NOT capturable (FusedTrainStep raises MmsaError when a capture is attempted with its side
+ *    streams on). Scratch memory is caller-provided (`ws`), sized by the matching *_ws_bytes().
  *  - return value: 0 = MMSA_OK, 1 = bad argument, 2 = launch failure, 3 = unsupported shape. No exceptions.
  *  - `dtype`: storage type of activations / working weights: 0 = fp32, 1 = bf16. Accumulation, statistics,
  *    parameters' gradients and optimizer state are always fp32.
@@ -213,20 +216,15 @@ typedef void (*mmsa_range_cb)(void* user, int64_t offset, int64_t length);
 int mmsa_bert_bwd_cb(const mmsa_bert_cfg* c, const float* w32, const void* wt, const int64_t* ids, const float* mask, void* ws,
                      const float* dfeat, float* grad, int32_t accumulate, void* stream, mmsa_range_cb cb, void* user,
                      int32_t layers_per_chunk, const uint8_t* frozen);
-/* The same with an optional second stream of the same device for the weight gradients (ignored when cb is set): every layer's
- * grouped weight-gradient launch is enqueued on wgrad_stream after an event that follows its operands' producers, the layers
- * alternate between two sets of gradient temporaries so that layer l's weight gradients overlap the backward chain of layer
- * l - 1, and the stream is joined into `stream` before the call returns. Results are bit-identical to mmsa_bert_bwd_cb. */
-int mmsa_bert_bwd_cb2(const mmsa_bert_cfg* c, const float* w32, const void* wt, const int64_t* ids, const float* mask, void* ws,
-                      const float* dfeat, float* grad, int32_t accumulate, void* stream, void* wgrad_stream, mmsa_range_cb cb,
-                      void* user, int32_t layers_per_chunk, const uint8_t* frozen);
 int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* c, const float* w32, const void* wt, void* ws, const float* dfeat, float* grad,
                        int32_t accumulate, void* stream, mmsa_range_cb cb, void* user, const uint8_t* frozen);
 /* The same with an optional second stream of the same device for the weight gradients: the stage-wise grouped weight-gradient
  * launches (mmsa_gemm_group_split's kernel) are enqueued on wgrad_stream, ordered after their stage's backward by an event and
  * joined into `stream` by an event before the call returns, so these throughput-bound launches overlap the latency-bound
- * BatchNorm / data-gradient chain of the following stages. Ignored (everything on `stream`) when cb is set or wgrad_stream is
- * null. Results are bit-identical to mmsa_resnet_bwd_cb. */
+ * BatchNorm / data-gradient chain of the following stages; the join happens on every exit path (errors included). With cb AND
+ * wgrad_stream set, every announced range is complete on wgrad_stream (it waits for an event recorded on `stream` right before each
+ * announcement): record the range's event there. wgrad_stream null: everything on `stream`. A backward after an inference-mode
+ * forward (cfg.training == 2: nothing was stored) returns MMSA_ERR_ARG. Results are bit-identical to mmsa_resnet_bwd_cb. */
 int mmsa_resnet_bwd_cb2(const mmsa_resnet_cfg* c, const float* w32, const void* wt, void* ws, const float* dfeat, float* grad,
                         int32_t accumulate, void* stream, void* wgrad_stream, mmsa_range_cb cb, void* user,
                         const uint8_t* frozen);

@@ -124,7 +124,6 @@ def _declare(L):
         "mmsa_bert_fwd": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp]),
         "mmsa_bert_bwd": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp, i32, vp]),
         "mmsa_bert_bwd_cb": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp, i32, vp, RANGE_CB, vp, i32, vp]),
-        "mmsa_bert_bwd_cb2": (ctypes.c_int, [P(BertCfg), vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, RANGE_CB, vp, i32, vp]),
         "mmsa_resnet_bwd_cb": (ctypes.c_int, [P(ResnetCfg), vp, vp, vp, vp, vp, i32, vp, RANGE_CB, vp, vp]),
         "mmsa_resnet_bwd_cb2": (ctypes.c_int, [P(ResnetCfg), vp, vp, vp, vp, vp, i32, vp, vp, RANGE_CB, vp, vp]),
         "mmsa_resnet_param_count": (ctypes.c_int, [P(ResnetCfg), i32]),

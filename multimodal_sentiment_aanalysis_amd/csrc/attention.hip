@@ -1052,7 +1052,7 @@ int attention_bwd(int impl, const void* qkv, const float* mask, const void* dctx
     case 32: return attn_bwd_mfma_nt<2>(qkv, mask, dctx, dqkv, B, heads, st);
     case 64: return attn_bwd_mfma_nt<4>(qkv, mask, dctx, dqkv, B, heads, st);
     case 128: {  // the recompute variant at S = 128 too: 19.68 vs 19.74 ms per step (MMSA_ATTN_BWD_RC=0: the image-keeping kernel)
-      static const bool rc = [] { const char* v = getenv("MMSA_ATTN_BWD_RC"); return !v || atoi(v) != 0; }();
+      static const bool rc = !mmsa_disabled("attn_bwd_rc");
       return rc ? attn_bwd_mfma_rc_nt<8>(qkv, mask, dctx, dqkv, B, heads, st)
                 : attn_bwd_mfma_nt<8>(qkv, mask, dctx, dqkv, B, heads, st);
     }

@@ -78,11 +78,7 @@ struct BertWs {
   std::vector<BertLayerWs> L;
   void *pooled, *dfeat_t, *dpool, *dprepool;
   void *bufA, *bufB, *bufC, *bufD, *bufI, *bufQ;
-  // second set of the gradient temporaries a layer's weight gradients read (ds2, dpre, dqkv) and the two ds1 buffers: with the
-  // weight gradients on their own stream the NEXT layer's backward must not overwrite them (layers alternate between the sets)
-  void *bufB2, *bufI2, *bufQ2, *bufS[2];
-  float* colws2;  // the weight-gradient stream's own column-sum scratch
-  size_t colws2_bytes;
+  void* bufS;  // ds1 of the current layer (read last, by the layer's grouped weight gradients)
   void* ones8;  // [B*S][8] bf16 ones (grouped bias gradients, engine_common.h)
   void *q_act, *q_w;     // fp8 mode: e4m3 copy of a Linear's input ([B*S][max(H, I)]); e4m3 image of the whole weight table
                          // (byte i = element i of the bf16 working copy; only the quantized Linears' ranges are written)
@@ -128,19 +124,13 @@ static BertWs bert_ws(const mmsa_bert_cfg& c, void* base) {
   w.bufD = b.take(M * H * es);
   w.bufI = b.take(M * I * es);
   w.bufQ = b.take(M * 3 * H * es);
-  w.bufB2 = b.take(M * H * es);
-  w.bufI2 = b.take(M * I * es);
-  w.bufQ2 = b.take(M * 3 * H * es);
-  w.bufS[0] = b.take(M * H * es);
-  w.bufS[1] = b.take(M * H * es);
+  w.bufS = b.take(M * H * es);
   // split-K slabs: the largest weight gradient is [I][H]; allow up to 8 slabs of it (pick_split respects the size)
   w.splitk_bytes = (size_t)8 * I * H * sizeof(float);
   w.splitk = (float*)b.take(w.splitk_bytes);
   size_t colb = colsum_ws_bytes((int)(3 * H > I ? 3 * H : I));
   w.colws = (float*)b.take(colb);
   w.colws_bytes = colb;
-  w.colws2 = (float*)b.take(colb);
-  w.colws2_bytes = colb;
   w.ones8 = b.take(M * 8 * 2);
   w.q_act = w.q_w = nullptr; w.q_wscales = w.q_rowscales = w.q_batchws = nullptr;
   if (c.dtype == MMSA_FP8) {
@@ -156,9 +146,9 @@ static BertWs bert_ws(const mmsa_bert_cfg& c, void* base) {
   return w;
 }
 
-// MMSA_NO_GELU_FACTOR=1: keep the pre-activation in a.pre and evaluate gelu' in the backward epilogue (A/B hook)
+// MMSA_DISABLE=gelu_factor: keep the pre-activation in a.pre and evaluate gelu' in the backward epilogue (A/B hook)
 static int gelu_factor() {
-  static const bool off = [] { const char* v = getenv("MMSA_NO_GELU_FACTOR"); return v && atoi(v) != 0; }();
+  static const bool off = mmsa_disabled("gelu_factor");
   return off ? 0 : 1;
 }
 
@@ -225,7 +215,7 @@ int mmsa_bert_fwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
     }
   }
   // (k = 0, 2: the input is a LayerNorm output whose per-token e4m3 image that LayerNorm wrote itself — no quantizer pass)
-  const bool ln_q = fp8 && !(H % 128) && !(getenv("MMSA_FP8_NO_LN_FUSE") && atoi(getenv("MMSA_FP8_NO_LN_FUSE")) != 0);
+  const bool ln_q = fp8 && !(H % 128) && !mmsa_disabled("fp8_ln_fuse");
   void* lnq = ln_q ? ws.q_act : nullptr;
   float* lnqs = ln_q ? ws.q_rowscales : nullptr;
   auto lin = [&](int l, int k, const void* x, long ldx, long woff, const float* bias, void* y, long ldy, int Mr, int N, int K, int act,
@@ -263,7 +253,7 @@ int mmsa_bert_fwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
 
 int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, const int64_t* ids, const float* mask,
                   void* ws_base, const float* dfeat, float* grad, int32_t accumulate, void* stream) {
-  return mmsa_bert_bwd_cb2(cp, w32, wt, ids, mask, ws_base, dfeat, grad, accumulate, stream, nullptr, nullptr, nullptr, 0, nullptr);
+  return mmsa_bert_bwd_cb(cp, w32, wt, ids, mask, ws_base, dfeat, grad, accumulate, stream, nullptr, nullptr, 0, nullptr);
 }
 
 // The backward with a "gradient range ready" callback: cb(user, offset, length) is called — on the host, from inside this
@@ -271,19 +261,11 @@ int mmsa_bert_bwd(const mmsa_bert_cfg* cp, const float* w32, const void* wt, con
 // `stream` (pooler + projection first, then `layers_per_chunk` encoder layers at a time from the last layer down, the
 // embeddings last). The data-parallel trainer records an event there and all-reduces that range on a side stream while
 // the remaining backward runs (fused.py GradReducer; Trainer.py:79-81 needs the REDUCED gradients only at the clip).
+// (Round 3 also carried a variant with the per-layer weight-gradient groups on a second stream: two persistent GEMMs that share
+//  the chip only stretch each other — it measured 0.13 ms per step slower and was removed in round 4)
 int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, const int64_t* ids, const float* mask,
                      void* ws_base, const float* dfeat, float* grad, int32_t accumulate, void* stream, mmsa_range_cb cb,
                      void* user, int32_t layers_per_chunk, const uint8_t* frozen) {
-  return mmsa_bert_bwd_cb2(cp, w32, wt, ids, mask, ws_base, dfeat, grad, accumulate, stream, nullptr, cb, user, layers_per_chunk, frozen);
-}
-
-// wgrad_stream (optional, another stream of the same device; ignored when cb is set): every layer's grouped weight-gradient
-// launch is enqueued there — after an event that follows the kernels producing its operands — and the layers alternate between
-// two sets of gradient temporaries, so layer l's weight gradients overlap the backward chain of layer l - 1; the stream is
-// joined into `stream` before the call returns. Bit-identical to mmsa_bert_bwd_cb.
-int mmsa_bert_bwd_cb2(const mmsa_bert_cfg* cp, const float* w32, const void* wt, const int64_t* ids, const float* mask,
-                      void* ws_base, const float* dfeat, float* grad, int32_t accumulate, void* stream, void* wgrad_stream,
-                      mmsa_range_cb cb, void* user, int32_t layers_per_chunk, const uint8_t* frozen) {
   if (!cp || !bert_cfg_ok(*cp) || !w32 || !wt || !ids || !ws_base || !dfeat || !grad) return MMSA_ERR_ARG;
   if (layers_per_chunk < 1) layers_per_chunk = 1;
   const mmsa_bert_cfg& c = *cp;
@@ -339,16 +321,6 @@ int mmsa_bert_bwd_cb2(const mmsa_bert_cfg* cp, const float* w32, const void* wt,
   }
   if (lowest == nl) return MMSA_OK;  // every encoder layer and the embeddings are frozen: the backward ends here
   void *dOut = ws.bufA, *bC = ws.bufC;
-  void* setB[2] = {ws.bufB, ws.bufB2};
-  void* setI[2] = {ws.bufI, ws.bufI2};
-  void* setQ[2] = {ws.bufQ, ws.bufQ2};
-  hipStream_t wst = (!cb && wgrad_stream && wgrad_stream != stream && sdt(c) == MMSA_BF16 && !Eng::force_simt()) ? (hipStream_t)wgrad_stream : nullptr;
-  Eng ew = e;  // the engine view of the weight-gradient stream: its own stream and column-sum scratch
-  ew.st = wst;
-  ew.col_ws = ws.colws2;
-  ew.col_ws_bytes = ws.colws2_bytes;
-  hipEvent_t set_free[2] = {nullptr, nullptr};  // recorded on wst after the weight gradients that read set p
-  auto drop_events = [&]() { for (hipEvent_t& ev : set_free) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; } };
   if (hipMemsetAsync(dOut, 0, (size_t)M * H * es, st) != hipSuccess) return MMSA_ERR_LAUNCH;
   RET_IF(e.linear_dgrad(ws.dprepool, H, W(lay.wp), dOut, (long)S * H, B, H, H));  // only the [CLS] rows receive gradient
   long chunk_end = lay.wp;  // encoder layers [l, ...) up to chunk_end are complete but not yet announced
@@ -359,30 +331,24 @@ int mmsa_bert_bwd_cb2(const mmsa_bert_cfg* cp, const float* w32, const void* wt,
     BertLayerWs& a = ws.L[l];
     const void* xin = l == 0 ? ws.x0 : ws.L[l - 1].out;
     const bool last_needed = (l == lowest);  // nothing trainable below: this layer's input needs no gradient
-    const int par = wst ? ((c.layers - 1 - l) & 1) : 0;  // which set of gradient temporaries this layer writes
-    if (wst && set_free[par]) {  // the weight gradients of layer l + 2 read this set: they must be done before it is rewritten
-      if (hipStreamWaitEvent(st, set_free[par], 0) != hipSuccess) { drop_events(); return MMSA_ERR_LAUNCH; }
-      (void)hipEventDestroy(set_free[par]);
-      set_free[par] = nullptr;
-    }
-    void* ds2 = setB[par];
+    void* ds2 = ws.bufB;
     // ds2 is also dY of the FFN output Linear: its bias gradient (column sums of ds2) comes out of the same pass
     // (a wholly frozen layer produces NO parameter gradient: its LayerNorm / bias gradient outputs are null, so that stale
     //  gradients of an earlier phase stay what torch would keep and a data-parallel replica never steps an un-reduced range)
     const bool lf = layer_frozen[l];
     RET_IF(layernorm_bwd(sdt(c), dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, lf ? nullptr : G(f.ln2w),
                          lf ? nullptr : G(f.ln2b), acc, ws.lnws, M, H, st, lf ? nullptr : G(f.b2)));
-    void* dpre = setI[par];
+    void* dpre = ws.bufI;
     RET_IF(e.linear_dgrad(ds2, H, W(f.w2), dpre, I, M, H, I, a.pre, I, nullptr, 0, gelu_factor()));  // * gelu'(pre), stored by the forward
     void* dh1 = bC;
     RET_IF(e.linear_dgrad(dpre, I, W(f.w1), dh1, H, M, I, H, nullptr, 0, ds2, H));  // + residual branch
-    void* ds1 = ws.bufS[par];  // (its own buffer: dOut / bC rotate under it while the weight gradients still read it)
+    void* ds1 = ws.bufS;  // (its own buffer: dOut / bC rotate under it and the grouped weight gradients read it last)
     RET_IF(layernorm_bwd(sdt(c), dh1, a.s1, a.mean1, a.rstd1, P(f.ln1w), ds1, lf ? nullptr : G(f.ln1w),
                          lf ? nullptr : G(f.ln1b), acc, ws.lnws, M, H, st,
                          lf ? nullptr : G(f.bo)));  // + bias gradient of the attention output Linear
     void* dctx = ws.bufD;
     RET_IF(e.linear_dgrad(ds1, H, W(f.wo), dctx, H, M, H, H));
-    void* dqkv = setQ[par];
+    void* dqkv = ws.bufQ;
     RET_IF(attention_bwd(aimpl, a.qkv, mask, dctx, dqkv, ws.attnws, B, S, c.heads, 64, st));
     void* dx = bC;
     if (!last_needed)
@@ -397,19 +363,7 @@ int mmsa_bert_bwd_cb2(const mmsa_bert_cfg* cp, const float* w32, const void* wt,
           {ds1, H, a.ctx, H, G(f.wo), nullptr, H, H},
           {dqkv, 3L * H, xin, H, G(f.wqkv), G(f.bqkv), 3 * H, H},
       };
-      if (wst) {
-        hipEvent_t ev;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { drop_events(); return MMSA_ERR_LAUNCH; }
-        const bool ok = hipEventRecord(ev, st) == hipSuccess && hipStreamWaitEvent(wst, ev, 0) == hipSuccess;
-        (void)hipEventDestroy(ev);
-        if (!ok) { drop_events(); return MMSA_ERR_LAUNCH; }
-        const int rc = ew.wgrad_group(jobs, 4, M, acc);
-        if (rc) { drop_events(); return rc; }
-        if (hipEventCreateWithFlags(&set_free[par], hipEventDisableTiming) != hipSuccess ||
-            hipEventRecord(set_free[par], wst) != hipSuccess) { drop_events(); return MMSA_ERR_LAUNCH; }
-      } else {
-        RET_IF(e.wgrad_group(jobs, 4, M, acc));
-      }
+      RET_IF(e.wgrad_group(jobs, 4, M, acc));
     }
     // rotate: dx becomes the next layer's dOut
     void* t = dOut; dOut = bC; bC = t;
@@ -419,15 +373,6 @@ int mmsa_bert_bwd_cb2(const mmsa_bert_cfg* cp, const float* w32, const void* wt,
       chunk_live = false;
     }
   }
-  // everything on the weight-gradient stream happens before what `stream` does after this call (and before the embedding
-  // backward below reuses the first set's buffer)
-  for (int p = 0; p < 2; ++p)
-    if (set_free[p]) {
-      const bool ok = hipStreamWaitEvent(st, set_free[p], 0) == hipSuccess;
-      (void)hipEventDestroy(set_free[p]);
-      set_free[p] = nullptr;
-      if (!ok) { drop_events(); return MMSA_ERR_LAUNCH; }
-    }
   if (lowest >= 0) return MMSA_OK;  // the embeddings are frozen
   // embeddings
   void* de = ws.bufB;

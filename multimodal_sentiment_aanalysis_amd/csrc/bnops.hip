@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
   }
 }
 static bool bn_small_ok(int dtype, int M, int training, const void* res, const void* mask) {
-  static const bool off = getenv("MMSA_BN_SMALL") && atoi(getenv("MMSA_BN_SMALL")) == 0;
+  static const bool off = mmsa_disabled("bn_small");
   return !off && dtype == MMSA_F32 && training && M <= BN_SMALL_ROWS && !res && !mask;
 }
 
@@ -489,7 +489,7 @@ static bool bn_small_ok(int dtype, int M, int training, const void* res, const v
 // 19.46 ms): every extra chunk is another partial row for the finalize kernels, 114 latency-bound launches per step.
 // MMSA_BN_RPL overrides (A/B hook).
 static int bn_rows_per_lane() {
-  static const int v = [] { const char* e = getenv("MMSA_BN_RPL"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 16; }();
+  static const int v = [] { const char* e = MMSA_EXP_ENV("MMSA_BN_RPL"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 16; }();
   return v;
 }
 

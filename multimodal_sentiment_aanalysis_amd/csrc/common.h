@@ -36,6 +36,35 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
     if (_e != hipSuccess) return MMSA_ERR_LAUNCH;             \
   } while (0)
 
+// ---- run-time switches (README.md "Switches") ---------------------------------------------------------------------------
+// MMSA_DISABLE=<name>[,<name>...] turns named fast paths off. Each one has a general form that stays compiled because some
+// problems need it anyway (a statistics pass where the convolution ran with a K split, one launch per weight gradient where the
+// group does not fit, ...); the parity tests compare the two forms in one process, so the variable is read at every call.
+// Names: conv_stats, parity_dgrad, bn_fold, bn_mask, bn_small, wgrad_defer, wgrad_group, bias_group, layer_group, group_order,
+// g2_2d, epi_spec, gelu_factor, fp8_ln_fuse, f32_tiny, bf16_tiny, attn_bwd_rc.
+#include <stdlib.h>
+#include <string.h>
+static inline bool mmsa_disabled(const char* name) {
+  const char* v = getenv("MMSA_DISABLE");
+  if (!v) return false;
+  const size_t n = strlen(name);
+  for (const char* p = v; *p;) {
+    const char* e = p;
+    while (*e && *e != ',') ++e;
+    if ((size_t)(e - p) == n && strncmp(p, name, n) == 0) return true;
+    p = *e ? e + 1 : e;
+  }
+  return false;
+}
+// Experiment hooks (cost-model overrides, forced K splits, timing-only ablations whose results are wrong, the 256 x 256 tile that
+// lost its A/B, diagnostics) exist only in builds made with -DMMSA_EXPERIMENTS (tools/microbench/build_variant.sh); the shipped
+// library never reads those variables and does not compile the code behind them.
+#ifdef MMSA_EXPERIMENTS
+#define MMSA_EXP_ENV(name) getenv(name)
+#else
+#define MMSA_EXP_ENV(name) ((const char*)nullptr)
+#endif
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }

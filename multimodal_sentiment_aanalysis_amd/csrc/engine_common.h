@@ -201,7 +201,7 @@ struct Eng {
       // fp32 in col_ws (every column holds db_g), picked up by one small kernel. The group's weight-gradient tiles do
       // not fill the chip (BERT-base layer: 216 tiles of 256x128 on 256 CUs), so the 9-12 extra tiles of a bias problem
       // run on CUs that were idle anyway — instead of a column-sum kernel + its finalize per bias (4 launches a layer).
-      static const bool no_bias_group = [] { const char* v = getenv("MMSA_NO_BIAS_GROUP"); return v && atoi(v) != 0; }();
+      static const bool no_bias_group = mmsa_disabled("bias_group");
       int nb = 0, bias_of[2] = {-1, -1};
       long scratch_off[2] = {0, 0};
       if (ones8 && !no_bias_group) {
@@ -254,7 +254,7 @@ struct Eng {
   // each); whatever does not group is launched on its own.
   int wgrad_batch(const GemmParams* jobs, int n) const {
     std::vector<char> done((size_t)n, 0);
-    static const bool off = [] { const char* v = getenv("MMSA_NO_WGRAD_GROUP"); return v && atoi(v) != 0; }();
+    static const bool off = mmsa_disabled("wgrad_group");
     const bool can_group = dtype == MMSA_BF16 && !force_simt() && !v1_only() && splitk_ws && !off;
     for (int i = 0; i < n; ++i) {
       if (done[i]) continue;

@@ -330,7 +330,7 @@ int gemm_f32_mfma_launch(const GemmParams& pin, hipStream_t st) {
   if (p.ws && p.ws_bytes > 0 && !(p.N % 4)) {
     const long tiles = (long)cdiv(p.M, FBM) * cdiv(p.N, FBN);
     int split = 1;
-    static const int target = [] { const char* v = getenv("MMSA_F32_TARGET_WGS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 768; }();
+    static const int target = [] { const char* v = MMSA_EXP_ENV("MMSA_F32_TARGET_WGS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 768; }();
     if (tiles < target) {
       split = (int)((target + tiles - 1) / tiles);
       const int maxs = p.K / 256;

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_tiny_multi_kernel(TinyBatch tb) {
 
 template <typename T>
 static bool tiny_eligible(const GemmParams& p) {
-  static const bool off = [] { const char* v = getenv("MMSA_F32_TINY"); return v && atoi(v) == 0; }();
+  static const bool off = mmsa_disabled("f32_tiny");
   if (off || p.gather != 0 || p.c_gw > 0 || p.M <= 0 || p.N <= 0 || p.K <= 0 || p.scale_a) return false;
   if (p.b_ones && (!p.b_kmajor || p.N != 1 || sizeof(T) != 4)) return false;
   // beyond: operand re-reads (no LDS sharing between the tiles of a workgroup) start to cost.  bf16: one notch higher so
@@ -153,7 +153,7 @@ static bool tiny_eligible(const GemmParams& p) {
 }
 bool gemm_f32_tiny_eligible(const GemmParams& p) { return tiny_eligible<float>(p); }
 bool gemm_bf16_tiny_eligible(const GemmParams& p) {
-  static const bool off = [] { const char* v = getenv("MMSA_BF16_TINY"); return v && atoi(v) == 0; }();
+  static const bool off = mmsa_disabled("bf16_tiny");
   return !off && p.M <= 128 && tiny_eligible<bf16>(p);
 }
 

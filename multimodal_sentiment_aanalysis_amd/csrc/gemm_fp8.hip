@@ -366,7 +366,7 @@ int gemm_fp8_launch(const GemmParams& pin, const float* scale_a, const float* sc
   q.scale_b = scale_b;
   const int slot = gemm_prof_open(q.g, st);
   {  // the persistent kernel's fp8 instantiation (gemm_mfma2.hip) when the shape suits it: K / lda / ldb in 2-byte units
-    static const bool simple = [] { const char* v = getenv("MMSA_FP8_SIMPLE"); return v && atoi(v) != 0; }();  // A/B hook
+    static const bool simple = [] { const char* v = MMSA_EXP_ENV("MMSA_FP8_SIMPLE"); return v && atoi(v) != 0; }();  // A/B hook
     GemmParams p2 = q.g;
     p2.K = pin.K / 2; p2.lda = pin.lda / 2; p2.ldb = pin.ldb / 2;
     p2.scale_a = scale_a; p2.scale_b = scale_b;

@@ -368,7 +368,7 @@ static int launch_variant2(const GemmParams& p, hipStream_t st) {
 }
 
 static bool use_regstage() {
-  const char* v = getenv("MMSA_GEMM_REGSTAGE");
+  const char* v = MMSA_EXP_ENV("MMSA_GEMM_REGSTAGE");
   return v && atoi(v) != 0;
 }
 
@@ -541,7 +541,7 @@ int gemm_bf16_launch(const GemmParams& pin, hipStream_t st) {
 // grouped weight-gradient launch (gemm_mfma2.hip) with one roofline record for the whole group
 int gemm_bf16_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st) {
   static const bool v1_only = [] { const char* v = getenv("MMSA_GEMM_V1"); return v && atoi(v) != 0; }();
-  static const bool no_group = [] { const char* v = getenv("MMSA_G2_NOGROUP"); return v && atoi(v) != 0; }();
+  static const bool no_group = mmsa_disabled("layer_group");
   if (v1_only || no_group || use_regstage()) return MMSA_ERR_UNSUPPORTED;
   if (!g_prof_on) return gemm2_launch_group(probs, colsum, n, st);
   std::lock_guard<std::recursive_mutex> lock(g_prof_mu);
@@ -601,13 +601,13 @@ static int gemm_bf16_launch_inner(const GemmParams& pin, hipStream_t st) {
     // byte extent of each operand view; the descriptor path needs every offset to fit a positive 32-bit int
     const long ea = p.a_kmajor ? ((long)(p.K - 1) * p.lda + p.M) * 2 : ((long)(p.M - 1) * p.lda + p.K) * 2;
     const long eb = p.b_kmajor ? ((long)(p.K - 1) * p.ldb + p.N) * 2 : ((long)(p.N - 1) * p.ldb + p.K) * 2;
-    const char* off = getenv("MMSA_GEMM_NO_SRD");
+    const char* off = MMSA_EXP_ENV("MMSA_GEMM_NO_SRD");
     p.use_srd = (p.gather == 0 && ea < 0x7FFFFFF0L && eb < 0x7FFFFFF0L && !(off && atoi(off))) ? 1 : 0;
     p.a_bytes = p.use_srd ? (unsigned)ea : 0;
     p.b_bytes = p.use_srd ? (unsigned)eb : 0;
     // timing-only diagnostic (results are wrong): zero-record descriptors make the range check drop every staging
     // load while the instruction stream, waits and barriers stay (cdna guide §7) — prices the memory side of the loop.
-    if (const char* nl = getenv("MMSA_GEMM_DBG_NOLOAD"))
+    if (const char* nl = MMSA_EXP_ENV("MMSA_GEMM_DBG_NOLOAD"))
       if (atoi(nl) && p.use_srd) { p.a_bytes = 0; p.b_bytes = 0; }
   }
   if (p.gather == 0) {

@@ -39,6 +39,14 @@
 #endif
 
 #define G2_MAX_GROUPS GEMM_MAX_GROUPS
+#define G2_ORDER_MAX 256
+// timing-only ablation switches of the main loop (MMSA_G2_DBG bitmask, results are wrong): run-time branches inside the K loop, so
+// they are compiled in experiment builds only (-DMMSA_EXPERIMENTS); the shipped kernels carry none of them
+#ifdef MMSA_EXPERIMENTS
+#define G2_DBG (s.dbg)
+#else
+#define G2_DBG 0
+#endif
 #ifdef G2_NO_SETPRIO  // experiment (tools/microbench/build_variant.sh -DG2_NO_SETPRIO): no priority raise around the MFMA blocks
 #define G2_SETPRIO(x) ((void)0)
 #else
@@ -66,6 +74,12 @@ struct G2Sched {
     int tile_begin, ntn;
     unsigned a_bytes, b_bytes, c_bytes;
   } grp[G2_MAX_GROUPS];
+  // grouped launches with <= G2_ORDER_MAX tiles: the walk order of the tiles (position -> tile index over all problems). The
+  // host orders them so that the contiguous run of tiles one XCD works on at a time is a compact block of one problem (few
+  // distinct A / B panels per K step in that XCD's L2) and a bias-gradient tile sits beside the weight-gradient tiles that
+  // read the same dY panel. 0 = the tiles are walked in index order.
+  int use_order;
+  unsigned short order[G2_ORDER_MAX];
   unsigned long long* stamp;  // in-kernel timing record or null
   unsigned colstat_bytes;
   float* colstat;        // per-64-row-slice column sums / sums of squares of the stored bf16 output (GemmParams::colstat) or null
@@ -191,6 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
           sp = (int)fd_div((uint32_t)item, s.fd_ntiles);
           gt = item - sp * s.ntiles;
         }
+        if (s.use_order) gt = s.order[gt];
         int g = 0;
 #pragma unroll
         for (int q = 1; q < G2_MAX_GROUPS; ++q)
@@ -1143,16 +1158,16 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
   __builtin_amdgcn_s_barrier();
   bf16x8 a0[4], b0[NJ], a1[4], b1[NJ];
   read_half(std::integral_constant<int, 0>{}, 0, a0, b0);
-  if (s.dbg & 2) read_half(std::integral_constant<int, 1>{}, 0, a1, b1);
+  if (G2_DBG & 2) read_half(std::integral_constant<int, 1>{}, 0, a1, b1);
 
   int eu1 = 0;    // store units of the counted epilogue that ended the previous step
   int st = 0;     // u % 3
   for (int u = 0; u < total; ++u) {
-    if (!(s.dbg & 2)) read_half(std::integral_constant<int, 1>{}, st, a1, b1);
+    if (!(G2_DBG & 2)) read_half(std::integral_constant<int, 1>{}, st, a1, b1);
     wait_lgkm<(RD_HALF < 14 ? RD_HALF : 14)>();  // first-half fragments (issued half a step ago) are in; 15 = "no wait"
     __builtin_amdgcn_sched_barrier(0);
     // second part of the refill started in the previous step (the DMA of step u+2, into the stage of step u-1)
-    if (u >= 1 && u + 2 < total && !(s.dbg & 1)) mma_half_dma(a0, b0, st == 0 ? 2 : st - 1, std::integral_constant<int, 1>{});
+    if (u >= 1 && u + 2 < total && !(G2_DBG & 1)) mma_half_dma(a0, b0, st == 0 ? 2 : st - 1, std::integral_constant<int, 1>{});
     else mma_half(a0, b0);
     __builtin_amdgcn_sched_barrier(0);
     const int nst = st == 2 ? 0 : st + 1;
@@ -1171,15 +1186,15 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
           default: wait_vm<NL + 2 * NSU>(); break;
         }
       }
-      if (!(s.dbg & 4)) __builtin_amdgcn_s_barrier();
-      if (!(s.dbg & 2)) read_half(std::integral_constant<int, 0>{}, nst, a0, b0);
+      if (!(G2_DBG & 4)) __builtin_amdgcn_s_barrier();
+      if (!(G2_DBG & 2)) read_half(std::integral_constant<int, 0>{}, nst, a0, b0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (u + 3 < total && !(s.dbg & 1)) mma_half_dma(a1, b1, st, std::integral_constant<int, 0>{});
+    if (u + 3 < total && !(G2_DBG & 1)) mma_half_dma(a1, b1, st, std::integral_constant<int, 0>{});
     else mma_half(a1, b1);
     int e = 0;
     if (++c_kt == C.nk) {
-      if (!(s.dbg & 8)) e = epilogue();
+      if (!(G2_DBG & 8)) e = epilogue();
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1277,7 +1292,7 @@ static inline int g2_epi_class(const GemmParams& p) {
 // Which epilogue instantiation a non-plain launch takes (gemm2_kernel's EPI): 2-5 = the specialised ones, which exist for the
 // plain (no gather) NT / NN problems; 1 = the general one. (0, the plain / slab store, is decided by the launcher.)
 static inline int g2_epi_kind(const GemmParams& p) {
-  static const bool off = [] { const char* v = getenv("MMSA_G2_NO_EPI_SPEC"); return v && atoi(v) != 0; }();  // A/B hook
+  static const bool off = mmsa_disabled("epi_spec");  // A/B hook
   if (off || p.a_kmajor || p.gather) return 1;
   if (p.out_f32 || p.act_after_add || (p.C2 && !p.c2_gelu_grad)) return 1;
   if (!p.mul && !p.add) {
@@ -1309,7 +1324,7 @@ struct G2Model { double a4, b4, a2, b2, c_split, d_split; };
 static const G2Model& g2_model() {
   static const G2Model m = [] {
     G2Model d{1.0, 0.06, 0.72, 0.05, 3.0, 2.0};
-    if (const char* v = getenv("MMSA_G2_MODEL")) {
+    if (const char* v = MMSA_EXP_ENV("MMSA_G2_MODEL")) {
       G2Model t = d;
       if (sscanf(v, "%lf,%lf,%lf,%lf,%lf,%lf", &t.a4, &t.b4, &t.a2, &t.b2, &t.c_split, &t.d_split) == 6) d = t;
     }
@@ -1326,7 +1341,7 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
   // The 256 x 256 tile is opt-in (MMSA_G2_BIG=1, or forced per launch with MMSA_G2_NJ=4:8): measured on MI355X it ties the
   // 256 x 128 tile on large NT / NN problems (both ~45 % of the MFMA-only time of the same loop) and loses on everything with
   // fewer than ~256 tiles; see DESIGN.md section 3 for the ablations.
-  static const bool no_big = [] { const char* v = getenv("MMSA_G2_BIG"); return !(v && atoi(v) != 0); }();
+  static const bool no_big = [] { const char* v = MMSA_EXP_ENV("MMSA_G2_BIG"); return !(v && atoi(v) != 0); }();
   // epilogue class: 0 plain store, 1 bias / activation / side output (registers only), 2 reads gelu' / residual operands
   const int epi = g2_epi_class(p);
   const G2Model& mdl = g2_model();
@@ -1370,7 +1385,7 @@ static G2Plan g2_plan_search(const GemmParams& p, int cus, size_t ws_bytes_avail
     static const double epi_cost_spec[2][6] = {{1.0, 1.0, 0.9, 0.65, 0.5, 4.0}, {2.0, 2.0, 1.2, 1.0, 0.8, 10.0}};
     const int kind = epi ? g2_epi_kind(p) : 0;
     const double* epi_cost_row = (kind == 2) ? epi_cost_spec[0] : (kind == 4 || kind == 5) ? epi_cost_spec[1] : epi_cost_gen[epi];
-    static const bool no_epi = [] { const char* v = getenv("MMSA_G2_NOEPI"); return v && atoi(v) != 0; }();  // A/B hook
+    static const bool no_epi = [] { const char* v = MMSA_EXP_ENV("MMSA_G2_NOEPI"); return v && atoi(v) != 0; }();  // A/B hook
     const double waste = (double)ntn * bn / p.N * ((double)ntm * bm / p.M);  // padding: only as a tie breaker
     for (int c = 0; c < nc; ++c) {
       const int per = cdiv(nsteps, cand[c]);
@@ -1462,11 +1477,14 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
       const int n = sscanf(f, "%d:%d", &a, &b);
       if (n == 2 && (a == 4 || a == 2) && b >= 1 && (b <= (a == 4 ? 4 : 2) || (a == 4 && b == 8)) && !(a == 4 && b < 2)) { fwm = a; fnj = b; }
       else if (n == 1 && ((a >= 2 && a <= 4) || a == 8)) { fwm = 4; fnj = a; }
+#ifndef MMSA_EXPERIMENTS
+      if (fnj == 8) { fwm = 0; fnj = 0; }  // (the 256 x 256 tile exists in experiment builds only)
+#endif
       if (fnj == 8 && (p.gather || p.scale_a || p.c_gw > 0 || p.colstat || p.mul || p.add || p.a_kmajor || (p.out_f32 && p.accumulate))) { fwm = 0; fnj = 0; }  // the forced shape does not exist for this problem
     }
     plan = fwm ? g2_plan_search(p, cus, ws_bytes_avail, fwm, fnj) : g2_plan(p, cus, ws_bytes_avail);
   }
-  if (const char* f = getenv("MMSA_G2_SPLIT")) {  // test hook: force the K split (needs a workspace that holds it)
+  if (const char* f = MMSA_EXP_ENV("MMSA_G2_SPLIT")) {  // test hook: force the K split (needs a workspace that holds it)
     const int sp = atoi(f);
     if (sp >= 1 && sp <= p.K / G2_BK && (sp == 1 || (p.ws && (size_t)sp * p.M * p.N * 4 <= ws_bytes_avail))) plan.split = sp;
   }
@@ -1483,13 +1501,14 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   s.fd_ntiles = make_fastdiv((uint32_t)s.ntiles);
   s.fd_ntn = make_fastdiv((uint32_t)s.ntn);
   s.rb = 0; s.cb = 0;
+  s.use_order = 0;
   s.fd_cb = make_fastdiv(1); s.fd_sbc = make_fastdiv(1);
   {
-    // On by default since round 3 (MMSA_G2_2D=0 turns it off): in round 2 it changed neither the stand-alone GEMM times nor the
+    // On by default since round 3 (MMSA_DISABLE=g2_2d turns it off): in round 2 it changed neither the stand-alone GEMM times nor the
     // step (the CUs of an XCD walk K in lock-step, so whoever shares a panel waits for the same fill either way) and only lowered
     // the L2-miss traffic the Infinity Cache absorbs; with the leaner round-3 kernels the same A/B reads 17.79-17.87 against
     // 18.02-18.11 ms/step (GEMM time 10.15 against 10.36 ms).
-    static const bool no2d = [] { const char* v = getenv("MMSA_G2_2D"); return v && atoi(v) == 0; }();
+    static const bool no2d = mmsa_disabled("g2_2d");
     // 2-D blocking when it lowers (2 rb + cb): A panel = 32 KiB, B panel = 16 KiB per K step and XCD
     int best_cb = 0;
     double best = 2.0 * 32.0 / s.ntn + s.ntn;  // row-major: a run of 32 tiles spans 32/ntn rows and all ntn columns
@@ -1523,7 +1542,7 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
       *p.colstat_rows = (int)rows;
     }
   }
-  if (const char* d = getenv("MMSA_G2_DBG")) s.dbg = atoi(d);
+  if (const char* d = MMSA_EXP_ENV("MMSA_G2_DBG")) s.dbg = atoi(d);
   s.c_bytes = s.split_k > 1 ? (unsigned)slab_bytes : (unsigned)(((long)(p.M - 1) * p.ldc + p.N) * (p.out_f32 ? 4 : 2));
   if (p.c_gw > 0) {
     if (s.split_k > 1) return MMSA_ERR_UNSUPPORTED;
@@ -1535,7 +1554,7 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
     p.a_bytes = (unsigned)ea; p.b_bytes = (unsigned)eb;
     // timing-only diagnostic (results are wrong): zero-record descriptors make the range check drop every staging
     // load while the instruction stream, waits and barriers stay — prices the memory side of the loop.
-    if (const char* nl = getenv("MMSA_GEMM_DBG_NOLOAD"))
+    if (const char* nl = MMSA_EXP_ENV("MMSA_GEMM_DBG_NOLOAD"))
       if (atoi(nl)) { p.a_bytes = 0; p.b_bytes = 0; }
   }
   const int grid = (int)(s.items < cus ? s.items : cus);
@@ -1543,17 +1562,13 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
   int rc;
   if (plan.wm == 4) {
     if (plan.nj == 8) {
+#ifdef MMSA_EXPERIMENTS  // the 256 x 256 tile (built in round 3, never faster: DESIGN.md section 3) is instantiated in experiment builds only
       if (!p.a_kmajor && !p.b_kmajor) rc = g2_launch_t<4, 8, false, false, 0>(p, s, grid, st);
       else if (!p.a_kmajor && p.b_kmajor) rc = g2_launch_t<4, 8, false, true, 0>(p, s, grid, st);
-      else rc = MMSA_ERR_UNSUPPORTED;  // (k-major A: the planner never picks the big tile)
-    }
-#ifdef G2_ONLY_BIG  // build-time probe (-DG2_ONLY_BIG): the 256 x 256 variants alone, for a quick resource-usage report
-#ifdef G2_ONLY_NT44   // (+ the 256 x 128 NT kernel with the general epilogue)
-    else if (plan.nj == 4) rc = g2_launch_e<4, 4, false, false, 0, false, 1>(p, s, grid, st);
+      else
 #endif
-    else rc = MMSA_ERR_UNSUPPORTED;
-  } else rc = MMSA_ERR_UNSUPPORTED;
-#else
+      rc = MMSA_ERR_UNSUPPORTED;
+    }
     else if (plan.nj == 4) rc = g2_launch_nj<4, 4>(p, s, grid, st);
     else if (plan.nj == 3) rc = g2_launch_nj<4, 3>(p, s, grid, st);
     else rc = g2_launch_nj<4, 2>(p, s, grid, st);
@@ -1561,7 +1576,6 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
     if (plan.nj == 2) rc = g2_launch_nj<2, 2>(p, s, grid, st);
     else rc = g2_launch_nj<2, 1>(p, s, grid, st);
   }
-#endif
   if (rc) return rc;
   if (s.split_k > 1) {
     launch_splitk_reduce<bf16>(p, st);
@@ -1596,6 +1610,47 @@ __global__ __launch_bounds__(256) void gemm2_group_reduce_kernel(G2GroupReduce a
     *(f32x4*)dst = v;
   }
   if (stamped) stamp_end(a.stamp);
+}
+
+// Walk order of a grouped launch's tiles (G2Sched::order). An XCD works on a contiguous run of ~tiles/8 positions at a time and
+// its L2 holds the panels of that run: a run of R tiles that spans r rows and c columns of one problem fetches r A panels (256 rows
+// of dY: 32 KiB per K step) and c B panels (128 columns of X: 16 KiB), so the order keeps runs compact — each problem is walked in
+// column blocks of ~sqrt(2 R) tiles, row by row inside a block (row-major for the narrow problems; the 24-column FFN-down weight
+// gradient of a BERT layer in three blocks of 8: its runs then touch 3 + 10 panels instead of 2 + 24) — and a problem that reads
+// the SAME A operand as an earlier one (a bias gradient: dY^T times a ones column) is dealt row by row into that problem's first
+// column block, right behind the weight-gradient tiles of the same dY panel, instead of re-reading all of dY on CUs of its own.
+// MMSA_DISABLE=group_order keeps the index order (A/B switch).
+static void g2_group_order(G2Sched& s, const GemmParams* probs, int n, int bm, int bn, int tiles) {
+  s.use_order = 0;
+  static const bool off = mmsa_disabled("group_order");
+  if (off || tiles > G2_ORDER_MAX || n < 2 || probs[0].gather != 0) return;
+  int rider_of[G2_MAX_GROUPS];  // rider_of[g] = the later problem with one column tile that shares g's A operand, or -1
+  bool is_rider[G2_MAX_GROUPS];
+  for (int g = 0; g < n; ++g) { rider_of[g] = -1; is_rider[g] = false; }
+  for (int g = 1; g < n; ++g)
+    for (int h = 0; h < g; ++h)
+      if (!is_rider[h] && rider_of[h] < 0 && probs[h].A == probs[g].A && probs[h].lda == probs[g].lda && probs[h].M == probs[g].M &&
+          cdiv(probs[g].N, bn) == 1) {
+        rider_of[h] = g; is_rider[g] = true;
+        break;
+      }
+  const int run = tiles < 8 ? 1 : (tiles + 7) / 8;
+  int target = 1;
+  while ((target + 1) * (target + 1) <= 2 * run) ++target;  // ~sqrt(2 R) columns per block
+  int pos = 0;
+  for (int g = 0; g < n; ++g) {
+    if (is_rider[g]) continue;
+    const int ntm = cdiv(probs[g].M, bm), ntn = s.grp[g].ntn;
+    const int nblk = ntn <= target + target / 2 ? 1 : cdiv(ntn, target);
+    const int cb = cdiv(ntn, nblk);
+    for (int c0 = 0; c0 < ntn; c0 += cb)
+      for (int tm = 0; tm < ntm; ++tm) {
+        for (int tn = c0; tn < ntn && tn < c0 + cb; ++tn) s.order[pos++] = (unsigned short)(s.grp[g].tile_begin + tm * ntn + tn);
+        if (c0 == 0 && rider_of[g] >= 0) s.order[pos++] = (unsigned short)(s.grp[rider_of[g]].tile_begin + tm);
+      }
+  }
+  if (pos != tiles) return;  // (cannot happen: every tile of every problem is dealt exactly once)
+  s.use_order = 1;
 }
 
 // Grouped launch: n (2..G2_MAX_GROUPS) independent weight-gradient problems C_g[M_g, N_g] = A_g^T B_g with the same K, both
@@ -1694,6 +1749,7 @@ int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hip
       slab_off += (long)plan.split * mn;
     }
   }
+  g2_group_order(s, probs, n, bm, bn, tiles);
   s.ntm = 1; s.ntn = 1; s.ntiles = tiles;
   s.nsteps = nsteps;
   s.split_k = plan.split;
@@ -1705,7 +1761,7 @@ int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hip
   s.fast = 1;
   s.stamp = probs[0].stamp;
   s.c_bytes = s.grp[0].c_bytes;
-  if (const char* d = getenv("MMSA_G2_DBG")) s.dbg = atoi(d);
+  if (const char* d = MMSA_EXP_ENV("MMSA_G2_DBG")) s.dbg = atoi(d);
   GemmParams p = probs[0];
   p.split_k = plan.split;
   p.accumulate = 0;
@@ -1714,13 +1770,6 @@ int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hip
   const int grid = s.items < cus ? s.items : cus;
   g2_last_plan[0] = plan.wm; g2_last_plan[1] = plan.nj; g2_last_plan[2] = plan.split;
   int rc;
-#ifdef G2_ONLY_BIG
-#ifdef G2_ONLY_GROUP  // (-DG2_ONLY_BIG -DG2_ONLY_GROUP: the grouped 256 x 128 TN kernel alone)
-  rc = g2_launch_t<4, 4, true, true, 0>(p, s, grid, st);
-#else
-  return MMSA_ERR_UNSUPPORTED;
-#endif
-#else
   if (plan.wm == 4) {
     if (plan.nj == 4) rc = g2_launch_nj<4, 4>(p, s, grid, st);
     else if (plan.nj == 3) rc = g2_launch_nj<4, 3>(p, s, grid, st);
@@ -1729,7 +1778,6 @@ int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hip
     if (plan.nj == 2) rc = g2_launch_nj<2, 2>(p, s, grid, st);
     else rc = g2_launch_nj<2, 1>(p, s, grid, st);
   }
-#endif
   if (rc) return rc;
   if (plan.split > 1) {
     red.n = n; red.split = plan.split; red.accumulate = accumulate; red.stamp = probs[0].stamp;

@@ -213,8 +213,7 @@ struct ConvStats {
   int rows;
 };
 static bool conv_stats_on() {
-  const char* v = getenv("MMSA_NO_CONV_STATS");  // read per call so that a test can compare both paths in one process
-  return !(v && atoi(v) != 0);
+  return !mmsa_disabled("conv_stats");  // (read per call so that a test can compare both paths in one process)
 }
 // z[B*Ho*Wo][Cout] = conv(x)
 // fold (inference): the convolution's weights with the BatchNorm scale folded in, its shift as the bias, activation, residual:
@@ -274,7 +273,7 @@ static int conv_dgrad(const ResCtx& r, const ConvDef& c, const void* dz, void* d
   // or ky = 1 (py = 0). Four GEMMs over a quarter of the rows each, 9 taps in total, instead of 9 taps on every row:
   // 4x fewer MFMAs. Each class stores through the output row map to its own pixels; together they cover dx once.
   if (c.k == 3 && c.stride == 2 && c.pad == 1 && !add && r.c.dtype == MMSA_BF16 && !Eng::force_simt() && !Eng::v1_only() &&
-      c.Hin == 2 * c.Hout && c.Win == 2 * c.Wout && !getenv("MMSA_NO_PARITY_DGRAD")) {
+      c.Hin == 2 * c.Hout && c.Win == 2 * c.Wout && !mmsa_disabled("parity_dgrad")) {
     GemmParams ps[4];
     bool ok = true;
     for (int cls = 0; cls < 4; ++cls) {
@@ -338,7 +337,7 @@ static int conv_wgrad(const ResCtx& r, const ConvDef& c, const void* dz, const v
 
 // the ReLU sign bits of a block output (MMSA_NO_BN_MASK=1: the backward reads the saved output instead; A/B hook)
 static unsigned char* bn_mask(const ConvWs& w, int act) {
-  static const bool off = [] { const char* v = getenv("MMSA_NO_BN_MASK"); return v && atoi(v) != 0; }();
+  static const bool off = mmsa_disabled("bn_mask");
   return (off || act != MMSA_ACT_RELU) ? nullptr : w.mask;
 }
 static int bn_fwd(const ResCtx& r, const ConvDef& c, const ConvWs& w, const void* res, void* y, int act, float* bnws,
@@ -428,8 +427,8 @@ int mmsa_resnet_fwd(const mmsa_resnet_cfg* cp, const float* w32, const void* wt,
   // (conv + BN + ReLU (+ residual) = one MFMA-tiled kernel, no BatchNorm launch, z never stored): per convolution two tiny
   // kernels turn the running statistics into scale / shift and write w' = w * scale[cout] (from the fp32 master weights) into a
   // scratch weight buffer; the GEMM runs on w' with the shift as its bias, the ReLU and the residual add in its epilogue.
-  // MMSA_NO_BN_FOLD=1: the unfolded eval path (A/B hook).
-  const bool infer = c.training == 2 && !(getenv("MMSA_NO_BN_FOLD") && atoi(getenv("MMSA_NO_BN_FOLD")) != 0);
+  // MMSA_DISABLE=bn_fold: the unfolded eval path (A/B hook).
+  const bool infer = c.training == 2 && !mmsa_disabled("bn_fold");
   auto fold_of = [&](const ConvDef& cd, const ConvWs& cw, int act, const void* res, ConvFold* f) -> int {
     const int K = cd.k * cd.k * cd.Cin;
     RET_IF(bn_fold(c.dtype, r.P(cd.g), r.P(cd.b), bnbuf + cd.rm, bnbuf + cd.rv, c.bn_eps, cd.Cout, cw.invstd, cw.mean,
@@ -519,13 +518,16 @@ int mmsa_resnet_bwd_cb(const mmsa_resnet_cfg* cp, const float* w32, const void* 
 }
 
 // wgrad_stream (optional, another stream of the same device): the stage-wise weight-gradient groups are enqueued there —
-// ordered after the stage's backward by an event, joined into `stream` by an event before the call returns — so that these
-// throughput-bound launches overlap the latency-bound BatchNorm / data-gradient chain of the following stages. Without a range
-// callback only (a callback announces a stage's gradients as enqueued on `stream`).
+// ordered after the stage's backward by an event, joined into `stream` by an event before the call returns (on EVERY exit path,
+// errors included: the caller recycles the workspace) — so that these throughput-bound launches overlap the latency-bound
+// BatchNorm / data-gradient chain of the following stages. With a range callback AND a weight-gradient stream (round 4: the
+// data-parallel step is the single-GPU step) every announced range is complete on wgrad_stream — it waits for an event recorded on
+// `stream` right before each announcement — so the caller records the range's event THERE.
 int mmsa_resnet_bwd_cb2(const mmsa_resnet_cfg* cp, const float* w32, const void* wt, void* ws_base, const float* dfeat,
                         float* grad, int32_t accumulate, void* stream, void* wgrad_stream, mmsa_range_cb cb, void* user,
                         const uint8_t* frozen) {
   if (!cp || !res_cfg_ok(*cp) || !w32 || !wt || !ws_base || !dfeat || !grad) return MMSA_ERR_ARG;
+  if (cp->training == 2) return MMSA_ERR_ARG;  // inference mode stored nothing a backward could use (include/mmsa.h)
   const mmsa_resnet_cfg& c = *cp;
   const ResLayout L = res_layout(c);
   ResWs ws = res_ws(c, L, ws_base);
@@ -562,8 +564,41 @@ int mmsa_resnet_bwd_cb2(const mmsa_resnet_cfg* cp, const float* w32, const void*
   if (!tail_frozen) {
     RET_IF(r.e.bias_grad(ws.dfeat_t, D, r.G(L.bproj), B, D, acc));
     RET_IF(r.e.linear_wgrad(ws.dfeat_t, D, ws.pooled, L.feat_c, r.G(L.wproj), B, D, L.feat_c, acc));
-    if (cb) cb(user, L.wproj, L.t.total - L.wproj);
   }
+  // (announced below, once the weight-gradient stream is known: a range is announced on the stream it is complete on)
+  const bool defer = c.dtype == MMSA_BF16 && !Eng::force_simt() && !Eng::v1_only() && !mmsa_disabled("wgrad_defer");
+  // ast: the stream the announcements are complete on (the caller's wgrad_stream whenever one is passed, also in the modes that
+  // launch every weight gradient in place); wst: where the deferred weight-gradient groups go
+  hipStream_t ast = (wgrad_stream && wgrad_stream != stream) ? (hipStream_t)wgrad_stream : nullptr;
+  hipStream_t wst = defer ? ast : nullptr;
+  bool wst_used = false;
+  auto wst_follows_st = [&]() -> int {  // what `stream` holds so far happens before what the weight-gradient stream does next
+    if (!ast) return MMSA_OK;
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return MMSA_ERR_LAUNCH;
+    const bool ok = hipEventRecord(ev, st) == hipSuccess && hipStreamWaitEvent(ast, ev, 0) == hipSuccess;
+    (void)hipEventDestroy(ev);  // (released once the recorded work has completed)
+    wst_used = true;
+    return ok ? MMSA_OK : MMSA_ERR_LAUNCH;
+  };
+  auto join_wst = [&]() -> int {  // everything enqueued on the weight-gradient stream happens before what `stream` does next
+    if (!wst_used) return MMSA_OK;
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return MMSA_ERR_LAUNCH;
+    const bool ok = hipEventRecord(ev, ast) == hipSuccess && hipStreamWaitEvent(st, ev, 0) == hipSuccess;
+    (void)hipEventDestroy(ev);
+    wst_used = false;
+    return ok ? MMSA_OK : MMSA_ERR_LAUNCH;
+  };
+  auto announce = [&](long off, long len) -> int {
+    if (!cb) return MMSA_OK;
+    RET_IF(wst_follows_st());
+    cb(user, off, len);
+    return MMSA_OK;
+  };
+  // everything below may have work in flight on the weight-gradient stream: it is joined on every exit path
+  auto run = [&]() -> int {
+  if (!tail_frozen) RET_IF(announce(L.wproj, L.t.total - L.wproj));
   if (lowest == nb) return MMSA_OK;  // stem and every bottleneck frozen
   RET_IF(r.e.linear_dgrad(ws.dfeat_t, D, r.W(L.wproj), ws.dpooled, L.feat_c, B, D, L.feat_c));
   void *dOut = ws.g0, *t1 = ws.g1, *t2 = ws.g2, *t3 = ws.g3;
@@ -571,28 +606,19 @@ int mmsa_resnet_bwd_cb2(const mmsa_resnet_cfg* cp, const float* w32, const void*
   long chunk_end = L.wproj;
   bool chunk_live = false;
   // Weight gradients are deferred to the end of their stage and launched in groups (Eng::wgrad_batch): every dz then lives in its
-  // own slot of the arena instead of the ping-pong buffer. MMSA_NO_WGRAD_DEFER=1 (A/B hook) and the non-bf16 modes launch them in place.
-  const bool defer = c.dtype == MMSA_BF16 && !Eng::force_simt() && !Eng::v1_only() &&
-                     !(getenv("MMSA_NO_WGRAD_DEFER") && atoi(getenv("MMSA_NO_WGRAD_DEFER")) != 0);
+  // own slot of the arena instead of the ping-pong buffer. MMSA_DISABLE=wgrad_defer (A/B hook) and the non-bf16 modes launch them in place.
   std::vector<GemmParams> pend;
   size_t arena_off = 0;
-  hipStream_t wst = (defer && !cb && wgrad_stream && wgrad_stream != stream) ? (hipStream_t)wgrad_stream : nullptr;
   Eng ew = r.e;  // the engine view of the weight-gradient stream: its own stream and its own slab workspace
   ew.st = wst;
   ew.splitk_ws = ws.splitk2;
-  bool wst_used = false;
   auto flush = [&]() -> int {
     int rc = MMSA_OK;
     if (!pend.empty()) {
       if (wst) {
-        hipEvent_t ev;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return MMSA_ERR_LAUNCH;
-        const bool ok = hipEventRecord(ev, st) == hipSuccess && hipStreamWaitEvent(wst, ev, 0) == hipSuccess;
-        (void)hipEventDestroy(ev);  // (released once the recorded work has completed)
-        if (!ok) return MMSA_ERR_LAUNCH;
+        RET_IF(wst_follows_st());
         for (GemmParams& q : pend) q.ws = ws.splitk2;
         rc = ew.wgrad_batch(pend.data(), (int)pend.size());
-        wst_used = true;
       } else {
         rc = r.e.wgrad_batch(pend.data(), (int)pend.size());
       }
@@ -600,15 +626,6 @@ int mmsa_resnet_bwd_cb2(const mmsa_resnet_cfg* cp, const float* w32, const void*
     pend.clear();
     if (!wst) arena_off = 0;  // (with a weight-gradient stream no slot is reused: the arena spans the whole net)
     return rc;
-  };
-  auto join_wst = [&]() -> int {  // everything enqueued on the weight-gradient stream happens before what `stream` does next
-    if (!wst_used) return MMSA_OK;
-    hipEvent_t ev;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return MMSA_ERR_LAUNCH;
-    const bool ok = hipEventRecord(ev, wst) == hipSuccess && hipStreamWaitEvent(st, ev, 0) == hipSuccess;
-    (void)hipEventDestroy(ev);
-    wst_used = false;
-    return ok ? MMSA_OK : MMSA_ERR_LAUNCH;
   };
   // where the dz of convolution cd goes: its arena slot (deferred) or the ping-pong buffer `fallback`
   auto dz_slot = [&](const ConvDef& cd, void* fallback, bool wg, void** out) -> int {
@@ -646,12 +663,11 @@ int mmsa_resnet_bwd_cb2(const mmsa_resnet_cfg* cp, const float* w32, const void*
     RET_IF(conv_dgrad(r, bd.c2, dz2, t3, nullptr));                                   // dy1 -> t3
     RET_IF(dz_slot(bd.c1, t1, wg, &dz1));
     RET_IF(bn_bwd(r, bd.c1, bw.c1, t3, nullptr, dz1, nullptr, MMSA_ACT_RELU, ws.bnws, wg));  // dz1
-    if (const char* dbg = getenv("MMSA_RESNET_BWD_STOP_BLOCK")) {  // diagnostic: leave t3 = dy1, t1 = dz1 of block i intact
+    if (const char* dbg = MMSA_EXP_ENV("MMSA_RESNET_BWD_STOP_BLOCK")) {  // diagnostic: leave t3 = dy1, t1 = dz1 of block i intact
       if (atoi(dbg) == i) {
         if (dz1 != t1 && hipMemcpyAsync(t1, dz1, (size_t)B * bd.c1.Hout * bd.c1.Wout * bd.c1.Cout * r.es, hipMemcpyDeviceToDevice, st) != hipSuccess)
           return MMSA_ERR_LAUNCH;
-        RET_IF(flush());
-        return join_wst();
+        return flush();
       }
     }
     if (wg) RET_IF(wgrad(bd.c1, dz1, xin));
@@ -671,13 +687,13 @@ int mmsa_resnet_bwd_cb2(const mmsa_resnet_cfg* cp, const float* w32, const void*
     }
     if (bd.has_ds || last_needed) {  // first bottleneck of a stage (or the last one needed): the stage's gradients are enqueued
       RET_IF(flush());
-      if (cb && chunk_live) cb(user, bd.c1.w, chunk_end - bd.c1.w);
+      if (chunk_live) RET_IF(announce(bd.c1.w, chunk_end - bd.c1.w));
       chunk_end = bd.c1.w;
       chunk_live = false;
     }
   }
   RET_IF(flush());
-  if (lowest >= 0) return join_wst();  // the stem is frozen
+  if (lowest >= 0) return MMSA_OK;  // the stem is frozen
   // max-pool, stem BN + ReLU, stem conv (weight gradient only: the image needs none)
   const ConvDef& s = L.stem;
   RET_IF(maxpool_bwd(c.dtype, dOut, ws.pool_idx, t1, B, s.Hout, s.Wout, 64, st));
@@ -692,8 +708,11 @@ int mmsa_resnet_bwd_cb2(const mmsa_resnet_cfg* cp, const float* w32, const void*
     RET_IF(r.e.gemm(p));
   }
   RET_IF(unpad_rows(ws.stem_dw, r.G(s.w), 64, L.Kstem_pad, 147, acc, st));
-  if (cb) cb(user, 0, chunk_end);
-  return join_wst();
+  return announce(0, chunk_end);
+  };
+  const int rc = run();
+  const int jrc = join_wst();
+  return rc ? rc : jrc;
 }
 
 }  // extern "C"

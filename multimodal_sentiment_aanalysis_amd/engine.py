@@ -208,7 +208,15 @@ class EngineModule(nn.Module):
         if cb is None or getattr(self, "_range_cb_for", None) is not hook:
             def trampoline(_user, off, length, _self=self):
                 h = getattr(_self, "_grad_range_hook", None)
-                if h is not None:
+                if h is None:
+                    return
+                # an engine that was handed a weight-gradient stream announces its ranges as complete on THAT stream
+                # (mmsa_resnet_bwd_cb2): make it current, so the reducer records the range's event where the range is produced
+                wst = getattr(_self, "_cb_stream", None)
+                if wst is not None:
+                    with torch.cuda.stream(wst):
+                        h(_self, int(off), int(length))
+                else:
                     h(_self, int(off), int(length))
             cb = RANGE_CB(trampoline)
             self._range_cb_obj, self._range_cb_for = cb, hook  # keep the ctypes thunk alive
@@ -249,9 +257,7 @@ class EngineModule(nn.Module):
         self._pending = None
 
     def use_wgrad_stream(self, on):
-        """The encoder's backward enqueues its weight-gradient groups (per ResNet stage / per BERT layer) on one more stream
-        (mmsa_resnet_bwd_cb2 / mmsa_bert_bwd_cb2; ignored under data parallelism, where gradients are announced on the
-        caller's stream)."""
+        """The image encoder's backward enqueues its stage-wise weight-gradient groups on one more stream (mmsa_resnet_bwd_cb2)."""
         self._wgrad_stream = (torch.cuda.Stream(device=self._flat_w.device) if on and self._flat_w is not None
                               and self._flat_w.is_cuda else None)
 
@@ -261,8 +267,8 @@ class EngineModule(nn.Module):
         if side is None:
             return None
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(side.device))  # (in the caller's thread: current_stream is thread-local)
-        side.wait_event(ev)  # (host-side enqueue of a wait: safe from any thread)
+        ev.record(torch.cuda.current_stream(side.device))
+        side.wait_event(ev)
         return side
 
     def _mark_pending(self, side):
@@ -270,35 +276,7 @@ class EngineModule(nn.Module):
         ev.record(side)
         self._pending = ev
 
-    def use_host_worker(self, on):
-        """With a side stream: the engine's C calls (each enqueues a few hundred kernels: 4-5 ms of host time) run on a worker
-        thread of their own, so the host enqueues both encoders at the same time (ctypes releases the GIL) — the two streams then
-        really have work from the start instead of one encoder's kernels arriving while the other's are half done. `join()`
-        waits for the worker before it joins the stream. Single-process only (a data-parallel step announces gradient ranges
-        from inside the call)."""
-        import concurrent.futures
-        old = getattr(self, "_worker", None)
-        if old is not None:
-            old.shutdown(wait=True)
-        self._worker = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="mmsa-enqueue") if on else None
-        self._inflight = None
-
-    def _submit(self, fn):
-        """Run fn (the stream-scoped engine call) on the worker thread if there is one, else inline."""
-        worker = getattr(self, "_worker", None)
-        if worker is None or getattr(self, "_side", None) is None:
-            fn()
-            return
-        prev = getattr(self, "_inflight", None)
-        if prev is not None:
-            prev.result()  # calls of one engine stay in order (and an exception of the previous one surfaces here)
-        self._inflight = worker.submit(fn)
-
     def join(self):
-        fut = getattr(self, "_inflight", None)
-        if fut is not None:
-            self._inflight = None
-            fut.result()
         ev = getattr(self, "_pending", None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
@@ -354,6 +332,9 @@ def materialize(root, device, precision=None):
         noff += len(e._nbt)
     state = FlatState(root, flat_w, flat_g, flat_wt, flat_bn, flat_nbt, ranges)
     root._flat_state = state
+    import weakref
+    for e in engs:
+        e._owner_state = weakref.ref(state)  # (fused._enclosing_state: an optimizer over a sub-module reuses these buffers)
     return state
 
 
@@ -398,12 +379,10 @@ class _BertFn(torch.autograd.Function):
     def backward(ctx, dfeat):
         eng = ctx.eng
         eng._ensure_grads()
-        wst = getattr(eng, "_wgrad_stream", None)  # the layers' weight-gradient groups on a stream of their own (use_wgrad_stream)
-        check(_lib.load().mmsa_bert_bwd_cb2(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ids),
-                                            ptr(ctx.mask), ptr(ctx.ws), ptr(dfeat.contiguous()), ptr(eng._flat_g),
-                                            eng._acc_flag(), stream_ptr(),
-                                            ctypes.c_void_p(wst.cuda_stream) if wst is not None else None, eng._range_cb(), None,
-                                            int(getattr(eng, "layers_per_chunk", 3)), eng._frozen_mask()), "mmsa_bert_bwd")
+        check(_lib.load().mmsa_bert_bwd_cb(ctypes.byref(ctx.cfg), ptr(eng._flat_w), ptr(ctx.wt), ptr(ctx.ids),
+                                           ptr(ctx.mask), ptr(ctx.ws), ptr(dfeat.contiguous()), ptr(eng._flat_g),
+                                           eng._acc_flag(), stream_ptr(), eng._range_cb(), None,
+                                           int(getattr(eng, "layers_per_chunk", 3)), eng._frozen_mask()), "mmsa_bert_bwd")
         eng._give_ws(ctx.ws)
         ctx.ws = None
         if getattr(eng, "_grad_ready_hook", None) is not None:
@@ -486,7 +465,7 @@ class _ResnetFn(torch.autograd.Function):
         if side is not None:  # allocated on the caller's stream, used on the side stream
             for t in (image, feat, ws):
                 t.record_stream(side)
-        eng._submit(enqueue)
+        enqueue()
         if dummy is None:
             eng._give_ws(ws)
         else:
@@ -510,6 +489,7 @@ class _ResnetFn(torch.autograd.Function):
                 # the stage-wise weight-gradient groups on a stream of their own (EngineModule.use_wgrad_stream), beside the
                 # latency-bound BatchNorm / data-gradient chain of the following stages; joined before the call returns
                 wst = getattr(eng, "_wgrad_stream", None)
+                eng._cb_stream = wst  # (see _range_cb: announcements are complete on the weight-gradient stream when there is one)
                 check(_lib.load().mmsa_resnet_bwd_cb2(ctypes.byref(cfg), ptr(eng._flat_w), ptr(wt), ptr(ws),
                                                       ptr(dfeat), ptr(eng._flat_g), acc_flag, stream_ptr(),
                                                       ctypes.c_void_p(wst.cuda_stream) if wst is not None else None,
@@ -520,7 +500,7 @@ class _ResnetFn(torch.autograd.Function):
                 if side is not None:
                     eng._mark_pending(side)
 
-        eng._submit(enqueue)
+        enqueue()
         return None, None, None
 
 

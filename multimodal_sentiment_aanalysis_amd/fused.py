@@ -286,6 +286,19 @@ class PhaseOptimizer:
             self.norm_history.append(self.adamw.norm_out.clone())
 
 
+def _enclosing_state(module):
+    """A valid FlatState (of some larger root) whose buffers already hold every engine of `module`, or None."""
+    engs = engines_of(module)
+    if not engs or any(e._flat_w is None for e in engs):
+        return None
+    st = getattr(engs[0], "_owner_state", None)
+    st = st() if callable(st) else st
+    if st is None or not st.valid():
+        return None
+    members = {id(e) for e, _, _ in st.ranges}
+    return st if all(id(e) in members for e in engs) else None
+
+
 class FlatAdam:
     """`optim.Adam(list(encoder.parameters()) + list(projection_head.parameters()), lr=lr)` / `optim.Adam(classifier.parameters(),
     lr=lr)` of the reference's two-stage pipeline (train.py:52,94) on the HIP optimizer kernel: Adam is AdamW with zero decay, and
@@ -298,6 +311,10 @@ class FlatAdam:
         for m in modules:
             st = getattr(m, "_flat_state", None)
             if st is None or not st.valid():
+                # a sub-module of an already materialized model: step the enclosing state's ranges instead of re-binding its
+                # engines into buffers of their own (which would invalidate the enclosing FlatState)
+                st = _enclosing_state(m)
+            if st is None:
                 dev = torch.device(device) if device is not None else next(m.parameters()).device
                 st = materialize(m, dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device()))
             params = list(m.parameters())
@@ -399,15 +416,6 @@ class FusedTrainStep:
         # ms/step on the same box; MMSA_WGRAD_STREAM=0 turns it off; ignored by the engine under data parallelism
         if self._image_net is not None and self.device.type == "cuda" and os.environ.get("MMSA_WGRAD_STREAM", "1") != "0":
             self._image_net.use_wgrad_stream(True)
-        # ... and its C calls on a host thread of their own (EngineModule.use_host_worker): both encoders are enqueued at the same
-        # time. Single process only. MMSA_HOST_WORKER=1 (experiment).
-        if (self._image_net is not None and self.device.type == "cuda" and two_streams and self.world == 1
-                and os.environ.get("MMSA_HOST_WORKER", "0") == "1"):
-            self._image_net.use_host_worker(True)
-        # experiment: the text encoder's per-layer weight-gradient groups on a stream of their own as well (mmsa_bert_bwd_cb2)
-        self._text_net = getattr(getattr(model, "encoder", None), "text_net", None)
-        if self._text_net is not None and self.device.type == "cuda" and os.environ.get("MMSA_BERT_WGRAD_STREAM", "0") == "1":
-            self._text_net.use_wgrad_stream(True)
         # optional: the two cross-modal transformers on side streams beside the fusion chain (MMSA_HEAD_STREAMS=1; A/B hook)
         self._head_streams = None
         if os.environ.get("MMSA_HEAD_STREAMS", "0") == "1" and hasattr(model, "use_head_streams") and self.device.type == "cuda":
@@ -435,6 +443,16 @@ class FusedTrainStep:
             raise _lib.MmsaError("flat parameter buffers were invalidated (model.to()/.float() after FusedTrainStep)")
         L = _lib.load()
         model = self.model
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # Stream capture of the step: only the single-stream form is capturable. With the side streams the step creates
+            # torch events, hands caching-allocator blocks to streams that were not forked from the capturing one
+            # (record_stream) and lets the encoder callbacks record on them — round 3's capture attempt crashed there. Refuse
+            # loudly instead (tools/microbench/graph_probe.py captures the single-stream step; a graph buys nothing here: the step
+            # is GPU-bound, DESIGN.md section 3 "Host side").
+            side = getattr(self._image_net, "_side", None) is not None or getattr(self._image_net, "_wgrad_stream", None) is not None
+            if side or self._head_streams is not None or self.reducer is not None:
+                raise _lib.MmsaError("FusedTrainStep.step cannot be stream-captured with its side streams on: build it with "
+                                     "two_streams=False and MMSA_WGRAD_STREAM=0 (single process) to capture the step")
         model.train(self.train_mode)
         if self.reducer is not None:
             self.reducer.begin_step()

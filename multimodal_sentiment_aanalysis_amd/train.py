@@ -14,8 +14,18 @@ from .engine import CrossEntropyLoss, nt_xent_loss, supcon_loss  # noqa: F401  (
 from .fused import FlatAdam
 
 
+def _flat_capable(module):
+    """Every parameter of `module` belongs to an engine inside it (only those live in flat buffers the HIP optimizer can step)."""
+    from .engine import engines_of
+    owned = {id(p) for e in engines_of(module) for p in e.parameters()}
+    params = list(module.parameters())
+    return bool(params) and all(id(p) in owned for p in params)
+
+
 def _adam(modules, lr, device, hip_optimizer):
-    if hip_optimizer and torch.device(device).type == "cuda":
+    # The reference's train.py accepts ANY nn.Module as encoder / head / classifier: a plain torch module (no engine inside, or
+    # parameters beside its engines) keeps torch.optim.Adam on its own tensors instead of failing in FlatAdam.
+    if hip_optimizer and torch.device(device).type == "cuda" and all(_flat_capable(m) for m in modules):
         return FlatAdam(modules, lr=lr, device=device)
     return optim.Adam([p for m in modules for p in m.parameters()], lr=lr)
 

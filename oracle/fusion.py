@@ -194,8 +194,9 @@ def supcon_two_view(z1, z2, labels, temperature=0.1):
 
 def nt_xent(z1, z2, temperature):
     """NT-Xent of the reference's ME-MHACL script (MML_ZYC/ME-MHACL/train.py:47-66): z = normalize(cat(z1, z2)); sim = z z^T with
-    the diagonal filled with -9e15, divided by T; loss = CE(sim, partner index). (That file is a script — its loss function
-    cannot be imported without running its data loading — so this restatement is pinned by reading only.)"""
+    the diagonal filled with -9e15, divided by T; loss = CE(sim, partner index). (That file is a script — it cannot be imported
+    without running its data loading; the golden tests/golden/n1_nt_xent.npz is made by calling its `contrastive_loss` alone,
+    lifted out of the parsed file with ast at generation time — tests/test_oracle_golden.py pins this restatement on it.)"""
     import torch.nn.functional as F
     B = z1.shape[0]
     z = F.normalize(torch.cat([z1, z2], 0), dim=1)

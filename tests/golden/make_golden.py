@@ -401,6 +401,32 @@ def gen_contrastive():
     npz("n1_contrastive.npz", **out)
 
 
+def gen_nt_xent():
+    """N1, label-free variant: the NT-Xent loss of the reference's ME-MHACL script (MML_ZYC/ME-MHACL/train.py:47-66), CALLED. The
+    file is a script whose top level loads a dataset and trains, so it cannot be imported; its `contrastive_loss` is a top-level
+    `def` that uses only torch and torch.nn.functional: the function's own node is lifted out of the parsed file (ast) and
+    compiled alone, in this container, at generation time — nothing else of the script runs, and no source text is stored.
+    Stored: inputs, temperature, loss, input gradients."""
+    import ast
+    import torch.nn.functional as F
+    path = "/root/reference/MML_ZYC/ME-MHACL/train.py"
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "contrastive_loss"]
+    assert len(fn) == 1, "ME-MHACL/train.py: expected one top-level contrastive_loss"
+    ns = {"torch": torch, "F": F}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    ref_nt_xent = ns["contrastive_loss"]
+    out = {}
+    for tag, B, D, T in (("a", 16, 128, 0.5), ("b", 64, 128, 0.1), ("c", 5, 32, 0.07), ("d", 32, 256, 1.0)):
+        z1 = rnd(B, D, seed=100 + B).requires_grad_(True)
+        z2 = rnd(B, D, seed=101 + B).requires_grad_(True)
+        loss = ref_nt_xent(z1, z2, T)
+        loss.backward()
+        out.update({f"ntxent.{tag}.z1": z1, f"ntxent.{tag}.z2": z2, f"ntxent.{tag}.T": torch.tensor(T),
+                    f"ntxent.{tag}.loss": loss, f"ntxent.{tag}.dz1": z1.grad, f"ntxent.{tag}.dz2": z2.grad})
+    npz("n1_nt_xent.npz", **out)
+
+
 # ------------------------------------------------------------------------------------------------ N2
 def gen_multitask_phases():
     """The reference's own MultiTaskTrainer (dataLoader/MultiTaskTrainer.py) CALLED on the identity-encoder fusion head: one
@@ -457,11 +483,13 @@ def gen_multitask_phases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["a1", "a2", "a4", "a5", "a7", "e1", "e2", "n1", "n2"]
+    which = sys.argv[1:] or ["a1", "a2", "a4", "a5", "a7", "e1", "e2", "n1", "n1x", "n2"]
     if "n2" in which:
         gen_multitask_phases()
     if "n1" in which:
         gen_contrastive()
+    if "n1x" in which:
+        gen_nt_xent()
     if "a1" in which:
         gen_cross_modal()
     if "a2" in which:

@@ -299,16 +299,16 @@ def test_resnet_engine_full_depth_bf16(dev, gamma3):
 
 def test_resnet_strided_dgrad_parity_classes(dev, monkeypatch):
     """The stride-2 3x3 data gradient as four parity-class GEMMs (resnet_engine.hip conv_dgrad) against the single row
-    gather over all pixels (MMSA_NO_PARITY_DGRAD=1): same forward, same bf16 rounding points, only the fp32 summation
+    gather over all pixels (MMSA_DISABLE=parity_dgrad): same forward, same bf16 rounding points, only the fp32 summation
     order of a dx element differs, so every parameter gradient must agree to bf16 resolution."""
     image, _, _, _ = synth_batch(4, 8, 96, 96, 10, seed=3)
     wgt = torch.randn(4, 256, generator=torch.Generator().manual_seed(9)).to(dev)
 
     def run(no_parity):
         if no_parity:
-            monkeypatch.setenv("MMSA_NO_PARITY_DGRAD", "1")
+            monkeypatch.setenv("MMSA_DISABLE", "parity_dgrad")
         else:
-            monkeypatch.delenv("MMSA_NO_PARITY_DGRAD", raising=False)
+            monkeypatch.delenv("MMSA_DISABLE", raising=False)
         torch.manual_seed(0)
         net = ResNetImageNet(MINI_RESNET)
         net.precision = "bf16"
@@ -334,13 +334,13 @@ def test_resnet_strided_dgrad_parity_classes(dev, monkeypatch):
 @pytest.mark.parametrize("rcfg,B,HW", [(MINI_RESNET, 4, 96), (dict(blocks=(3, 4, 6, 3), widths=(64, 128, 256, 512)), 8, 128)])
 def test_resnet_weight_gradients_grouped_per_stage(dev, monkeypatch, rcfg, B, HW):
     """The weight gradients of a stage deferred to its end and launched in groups with one common K split (Eng::wgrad_batch ->
-    mmsa_gemm_group_split's kernel) against launching each in place (MMSA_NO_WGRAD_DEFER=1): same forward, same dz values (they
+    mmsa_gemm_group_split's kernel) against launching each in place (MMSA_DISABLE=wgrad_defer): same forward, same dz values (they
     only live in another buffer), so every gradient agrees to the fp32 summation order of its K slices; fewer MFMA launches."""
     image, _, _, _ = synth_batch(B, 8, HW, HW, 10, seed=3)
     wgt = torch.randn(B, 256, generator=torch.Generator().manual_seed(9)).to(dev)
 
     def run(defer):
-        monkeypatch.setenv("MMSA_NO_WGRAD_DEFER", "0" if defer else "1")
+        monkeypatch.setenv("MMSA_DISABLE", "" if defer else "wgrad_defer")
         torch.manual_seed(0)
         net = ResNetImageNet(rcfg)
         net.precision = "bf16"
@@ -368,13 +368,13 @@ def test_resnet_weight_gradients_grouped_per_stage(dev, monkeypatch, rcfg, B, HW
 @pytest.mark.parametrize("rcfg,B,HW", [(MINI_RESNET, 4, 96), (dict(blocks=(3, 4, 6, 3), widths=(64, 128, 256, 512)), 8, 128)])
 def test_conv_epilogue_statistics_match_the_statistics_pass(dev, monkeypatch, rcfg, B, HW):
     """BatchNorm batch statistics taken in the convolution GEMM's epilogue (GemmParams::colstat: per 64-row slice column sums of
-    the bf16 values the epilogue stores) against the separate streamed statistics pass over z (MMSA_NO_CONV_STATS=1): the same
+    the bf16 values the epilogue stores) against the separate streamed statistics pass over z (MMSA_DISABLE=conv_stats): the same
     numbers summed in another order — mean / variance agree to fp32 rounding, so the normalised activations are the same bf16
     values up to rare one-ulp flips, through all 53 BatchNorms of ResNet-50; fewer kernels are launched."""
     L = _lib.load()
 
     def run(fused):
-        monkeypatch.setenv("MMSA_NO_CONV_STATS", "0" if fused else "1")
+        monkeypatch.setenv("MMSA_DISABLE", "" if fused else "conv_stats")
         net, sd, ocfg, image, wgt = _resnet_case(rcfg, B, HW, dev)
         net.to(dev).train()
         out = net(image.to(dev))
@@ -404,7 +404,7 @@ def test_conv_epilogue_statistics_match_the_statistics_pass(dev, monkeypatch, rc
 def test_resnet_inference_folds_batchnorm_into_the_convolutions(dev, monkeypatch, precision, tol):
     """Eval mode without a backward (torch.no_grad): mmsa_resnet_fwd runs with training = 2 — every BatchNorm folded into the GEMM
     epilogue of the convolution in front of it (conv + BN + ReLU (+ residual add) = one kernel; no BatchNorm launch, z never
-    stored). Against the oracle's eval-mode forward, against the unfolded eval path of the same engine (MMSA_NO_BN_FOLD=1), and
+    stored). Against the oracle's eval-mode forward, against the unfolded eval path of the same engine (MMSA_DISABLE=bn_fold), and
     with fewer kernel launches than it (GEMM launch count equal: the fold adds none)."""
     torch.manual_seed(1)
     rcfg = dict(blocks=(2, 1, 1, 2), widths=(64, 64, 128, 128))
@@ -427,9 +427,9 @@ def test_resnet_inference_folds_batchnorm_into_the_convolutions(dev, monkeypatch
     net.to(dev).eval()
     with torch.no_grad():
         out = net(image.to(dev))
-        monkeypatch.setenv("MMSA_NO_BN_FOLD", "1")
+        monkeypatch.setenv("MMSA_DISABLE", "bn_fold")
         unfolded = net(image.to(dev))
-        monkeypatch.setenv("MMSA_NO_BN_FOLD", "0")
+        monkeypatch.setenv("MMSA_DISABLE", "")
     assert rel_err(out, ref) < tol, f"folded inference vs oracle ({precision}): {rel_err(out, ref)}"
     assert rel_err(out, unfolded) < tol, f"folded vs unfolded eval path: {rel_err(out, unfolded)}"
     # eval mode WITH a backward keeps the unfolded path (the backward needs z and the statistics) and still matches
@@ -745,10 +745,8 @@ def test_image_encoder_on_its_own_stream_changes_nothing(dev, monkeypatch, full)
                        for r in range(ids.shape[0])]).to(ids.dtype)  # no token twice in a row: no atomic meets another
     batch = (image.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
 
-    def run(two, wgrad_stream=False, bert_wgrad_stream=False, host_worker=False):
-        monkeypatch.setenv("MMSA_HOST_WORKER", "1" if host_worker else "0")
+    def run(two, wgrad_stream=False):
         monkeypatch.setenv("MMSA_WGRAD_STREAM", "1" if wgrad_stream else "0")
-        monkeypatch.setenv("MMSA_BERT_WGRAD_STREAM", "1" if bert_wgrad_stream else "0")
         torch.manual_seed(0)
         step = FusedTrainStep(mk(), dev, precision="bf16", lr=1e-3, two_streams=two)
         assert step.two_streams == two and (getattr(step._image_net, "_side", None) is not None) == two
@@ -764,12 +762,7 @@ def test_image_encoder_on_its_own_stream_changes_nothing(dev, monkeypatch, full)
     a, b = run(True), run(False)
     # ... and with the image encoder's stage-wise weight-gradient groups on a third stream (mmsa_resnet_bwd_cb2)
     c = run(True, wgrad_stream=True)
-    # ... and with the text encoder's per-layer weight-gradient groups on a stream of their own too (mmsa_bert_bwd_cb2:
-    # alternating sets of gradient temporaries, event-ordered reuse)
-    d = run(True, wgrad_stream=True, bert_wgrad_stream=True)
-    # ... and with the image encoder's C calls enqueued from a host thread of their own (EngineModule.use_host_worker)
-    e = run(True, wgrad_stream=True, host_worker=True)
-    for other, name in ((a, "two-stream"), (c, "three-stream"), (d, "four-stream"), (e, "host-worker")):
+    for other, name in ((a, "two-stream"), (c, "three-stream")):
         for (la, ga), (lb, gb) in zip(other[0], b[0]):
             assert torch.equal(la, lb) and torch.equal(ga, gb), name
         for x, y, what in zip(other[1:], b[1:], ("weights", "exp_avg", "exp_avg_sq", "BatchNorm buffers")):

@@ -281,7 +281,16 @@ def test_e2_resnet_mini_against_transformers(dev):
             errs.append(e)
             worst = max(worst, (n, e), key=lambda t: t[1])
         if precision == "fp32":
-            assert worst[1] < tol_g, f"{precision}: worst gradient rel-L2 {worst[1]:.3e} at {worst[0]}"
+            # the loose bound is for the BatchNorm shifts only (badly conditioned column sums: the next BatchNorm is invariant to
+            # most of a per-channel shift); every other tensor keeps the tight one. The stem's BN bias is ALSO pinned at 0.15 in
+            # the teacher-forced backward test (tests/test_engines_gpu.py::test_resnet_backward_teacher_forced).
+            named = [(n, e) for (n, _), e in zip([(n, p) for n, p in net.named_parameters() if n.startswith("resnet.")], errs)]
+            loose = [(n, e) for n, e in named if n.endswith(".bias")]
+            tight = [(n, e) for n, e in named if not n.endswith(".bias")]
+            wl, wt_ = max(loose, key=lambda t: t[1]), max(tight, key=lambda t: t[1])
+            print(f"e2 mini fp32 gradients: worst BN shift {wl[1]:.2e} at {wl[0]}; worst other {wt_[1]:.2e} at {wt_[0]}")
+            assert wl[1] < tol_g, f"{precision}: worst BatchNorm-shift gradient rel-L2 {wl[1]:.3e} at {wl[0]}"
+            assert wt_[1] < 6e-3, f"{precision}: worst weight / scale gradient rel-L2 {wt_[1]:.3e} at {wt_[0]}"
         else:
             # Free-running bf16 on a random-init BatchNorm net with 4 samples (36 of them per channel in the last stage): two correct
             # implementations decorrelate. The yardstick is the ORACLE under the bf16 storage policy on the
@@ -768,9 +777,21 @@ def test_c4_fp8_b128_workload(dev):
 
 def test_n1_nt_xent_variant(dev):
     """The label-free NT-Xent of the reference's ME-MHACL script (ME-MHACL/train.py:47-66) = the two-view kernel with every
-    sample its own class; against the oracle's restatement (that file is a script: pinned by reading) and its autograd."""
+    sample its own class: against the golden made by CALLING the reference's own function (tests/golden/n1_nt_xent.npz,
+    make_golden.py::gen_nt_xent) and, on more shapes, against the oracle's restatement and its autograd."""
     from multimodal_sentiment_aanalysis_amd.engine import nt_xent_loss
     from oracle import fusion as OF
+    d = load("n1_nt_xent.npz")
+    for tag in "abcd":
+        x = d[f"ntxent.{tag}.z1"].to(dev).requires_grad_(True)
+        y = d[f"ntxent.{tag}.z2"].to(dev).requires_grad_(True)
+        loss = nt_xent_loss(x, y, float(d[f"ntxent.{tag}.T"]))
+        loss.backward()
+        ref = d[f"ntxent.{tag}.loss"].item()
+        assert abs(loss.item() - ref) < 2e-5 * max(1.0, abs(ref)), (tag, loss.item(), ref)
+        scale = max(d[f"ntxent.{tag}.dz1"].abs().max().item(), d[f"ntxent.{tag}.dz2"].abs().max().item())
+        assert (x.grad.cpu() - d[f"ntxent.{tag}.dz1"]).abs().max().item() < 1e-4 * scale, tag
+        assert (y.grad.cpu() - d[f"ntxent.{tag}.dz2"]).abs().max().item() < 1e-4 * scale, tag
     for B, D, T in ((16, 128, 0.5), (64, 128, 0.1), (5, 32, 0.5)):
         g = torch.Generator().manual_seed(B)
         z1, z2 = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)

@@ -313,3 +313,18 @@ def test_n1_contrastive_losses():
         close(loss, d[f"supcon.{tag}.loss"], 1e-6, f"supcon {tag} loss")
         close(z1.grad, d[f"supcon.{tag}.dz1"], 1e-5, f"supcon {tag} dz1")
         close(z2.grad, d[f"supcon.{tag}.dz2"], 1e-5, f"supcon {tag} dz2")
+
+
+def test_n1_nt_xent_against_reference_function():
+    """The oracle's NT-Xent (oracle/fusion.py::nt_xent) against values and gradients produced by CALLING the reference's own
+    `contrastive_loss` of MML_ZYC/ME-MHACL/train.py:47-66 (the function's node lifted out of the script with ast at generation
+    time: tests/golden/make_golden.py::gen_nt_xent)."""
+    d = load("n1_nt_xent.npz")
+    for tag in "abcd":
+        z1 = d[f"ntxent.{tag}.z1"].clone().requires_grad_(True)
+        z2 = d[f"ntxent.{tag}.z2"].clone().requires_grad_(True)
+        loss = OF.nt_xent(z1, z2, float(d[f"ntxent.{tag}.T"]))
+        loss.backward()
+        close(loss, d[f"ntxent.{tag}.loss"], 1e-6, f"nt-xent {tag} loss")
+        close(z1.grad, d[f"ntxent.{tag}.dz1"], 1e-5, f"nt-xent {tag} dz1")
+        close(z2.grad, d[f"ntxent.{tag}.dz2"], 1e-5, f"nt-xent {tag} dz2")

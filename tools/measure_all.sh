@@ -2,7 +2,8 @@
 # The round's measurement set on the GPU box: tools/measure_all.sh <prefix>  (then, back home: tools/publish_profiles.sh <prefix>)
 set -e -o pipefail
 P=${1:-f}
-python -m pytest tests -m gpu -q > gpurun_out/${P}_tests.log 2>&1 || echo "TESTS FAILED (measurements continue)"
+# a red test run stops the measurement set: published numbers always come from a build whose GPU tests pass
+python -m pytest tests -m gpu -q > gpurun_out/${P}_tests.log 2>&1 || { tail -30 gpurun_out/${P}_tests.log; echo "TESTS FAILED: no measurements taken"; exit 1; }
 tail -1 gpurun_out/${P}_tests.log
 MMSA_PROF_DUMP=gpurun_out/${P}_shapes.csv python3 bench.py > gpurun_out/${P}_bench.json 2> gpurun_out/${P}_bench.err
 cut -c1-160 gpurun_out/${P}_bench.json

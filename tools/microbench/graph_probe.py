@@ -1,11 +1,15 @@
 """Feasibility probe: capture one FusedTrainStep.step into a torch.cuda.CUDAGraph (hipGraph) and replay it. dropout = 0 (the fusion
-head's dropout seed is a per-call host value), constant learning rate."""
+head's dropout seed is a per-call host value), constant learning rate. Run it with MMSA_TWO_STREAMS=0 MMSA_WGRAD_STREAM=0: the
+step refuses a capture with its side streams on (fused.py). PROBE_FORCE=1 bypasses that refusal for ONE diagnostic run of the
+three-stream capture (round 3's crash; keep AMD_LOG_LEVEL=3 output and the faulthandler trace under gpurun_out/)."""
 import faulthandler, os, sys, time, torch
 faulthandler.enable()
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench
 import multimodal_sentiment_aanalysis_amd as mm
 from multimodal_sentiment_aanalysis_amd.fused import FusedTrainStep
+if os.environ.get("PROBE_FORCE") == "1":
+    torch.cuda.is_current_stream_capturing = lambda: False  # diagnostic only: lets the guarded step run under capture
 dev = torch.device("cuda:0")
 B = int(os.environ.get("PROBE_B", "64"))
 batch = bench.synth_batch(B, 128, 30522, dev, 1234)
