@@ -360,6 +360,24 @@ def main(argv=None):
                    "gemm_tflops": round(g_tf, 2), "gemm_frac_of_peak": round(g_tf / peak, 4),
                    "gemm_ms": round(fms.value / STAMP_STEPS, 3), "gemm_launches": fn_.value // STAMP_STEPS,
                    "what": "training-mode forward of the same model and batch, no autograd; 30 passes after the timed steps"}
+    # (2b) N > 1: how long a step WAITS for the gradient collectives the backward did not hide — timing events on the compute stream
+    #      around the join with the collective stream (GradReducer.finish), five extra steps after the timed regions
+    collective = None
+    if world > 1 and args.mode == "train" and getattr(trainer, "reducer", None) is not None:
+        trainer.exposed_events = []
+        for _ in range(5):
+            trainer.step(*batch)
+        sync()
+        ex = sorted(e0.elapsed_time(e1) for e0, e1 in trainer.exposed_events)
+        trainer.exposed_events = None
+        ex_t = torch.tensor([ex[len(ex) // 2]], dtype=torch.float64, device=device)
+        dist.all_reduce(ex_t, op=dist.ReduceOp.MAX)
+        collective = {"exposed_ms_per_step": round(ex_t.item(), 3),
+                      "form": "reduce-scatter + sharded AdamW + all-gather" if getattr(trainer, "shard_optimizer", False) else "all-reduce",
+                      "payload": getattr(trainer.reducer, "payload", "fp32"),
+                      "collectives_per_step": len(trainer.reducer.issued),
+                      "what": "median over 5 steps (max over ranks) of the time the compute stream waits at the join with the "
+                              "collective stream before the clip; the all-gather of the reduce-scatter form is not included"}
     # (3b) the tolerance-meeting mode beside the headline (north_star: logits within 1e-3, loss within 1e-4 of the CPU reference
     #      — met by precision="fp32", tests/test_golden_gpu.py::test_c0_full_size_fp32; bf16 storage cannot):
     #      a second model from the same seed (= the same initial weights), --exact-steps timed steps of the exact mode on the same
@@ -466,6 +484,8 @@ def main(argv=None):
             out["forward"] = fwd
         if exact is not None:
             out["exact_mode"] = exact
+        if collective is not None:
+            out["collective"] = collective
         if loss is not None:
             out["loss"] = round(float(loss), 5)
         if cpu is not None:

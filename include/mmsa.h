@@ -307,6 +307,14 @@ int mmsa_grad_norm_guard(const float* g, int64_t n, float grad_scale, float max_
 int mmsa_grad_norm_ranges(const float* g, const int64_t* offsets, const int64_t* lengths, int32_t nranges, float grad_scale,
                           float max_norm, const float* loss, int32_t* step_count, float* norm_out /*[4]*/, void* ws,
                           float beta1, float beta2, void* stream);
+/* The two halves of mmsa_grad_norm_ranges as separate calls (same reference lines: clip_grad_norm_, Trainer.py:80): the sum of
+ * squares over `nranges` ranges (0 allowed) left as ONE device double in sumsq[0], and the finalize over n such doubles (their sum ->
+ * norm, clip coefficient, skip flag, step count, bias corrections as mmsa_grad_norm_guard). Used by the reduce-scatter form of the
+ * data-parallel step (every rank sums the squares of the reduced gradient shards it owns; a one-element all-reduce adds them) */
+int mmsa_grad_sumsq_ranges(const float* g, const int64_t* offsets, const int64_t* lengths, int32_t nranges, double* sumsq /*[1]*/,
+                           void* ws, void* stream);
+int mmsa_grad_norm_from_sumsq(const double* sumsq, int32_t n, float grad_scale, float max_norm, const float* loss,
+                              int32_t* step_count, float* norm_out /*[4]*/, float beta1, float beta2, void* stream);
 /* g[0, n) *= norm_clip[1] (no-op on a skipped step): the in-place scaling clip_grad_norm_ applies to gradients that no
  * optimizer owns (phase 3 of dataLoader/MultiTaskTrainer.py:147-177 clips four modules and steps one) */
 int mmsa_grad_scale_clip(float* g, int64_t n, const float* norm_clip, void* stream);

@@ -148,6 +148,8 @@ def _declare(L):
         "mmsa_adamw_step": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp]),
         "mmsa_grad_norm_guard": (ctypes.c_int, [vp, i64, f32, f32, vp, vp, vp, vp, f32, f32, vp]),
         "mmsa_grad_norm_ranges": (ctypes.c_int, [vp, i64p, i64p, i32, f32, f32, vp, vp, vp, vp, f32, f32, vp]),
+        "mmsa_grad_sumsq_ranges": (ctypes.c_int, [vp, i64p, i64p, i32, vp, vp, vp]),
+        "mmsa_grad_norm_from_sumsq": (ctypes.c_int, [vp, i32, f32, f32, vp, vp, vp, f32, f32, vp]),
         "mmsa_grad_scale_clip": (ctypes.c_int, [vp, i64, vp, vp]),
         "mmsa_adamw_step_dev": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, f32, vp]),
         "mmsa_cast_f32": (ctypes.c_int, [i32, vp, vp, i64, vp]),

@@ -162,6 +162,16 @@ int mmsa_grad_norm_ranges(const float* g, const int64_t* offsets, const int64_t*
   return grad_norm_ranges(g, (const long*)offsets, (const long*)lengths, nranges, grad_scale, max_norm, norm_out, ws,
                           (hipStream_t)stream, loss, step_count, beta1, beta2);
 }
+int mmsa_grad_sumsq_ranges(const float* g, const int64_t* offsets, const int64_t* lengths, int32_t nranges, double* sumsq, void* ws,
+                           void* stream) {
+  if (!g || !sumsq || !ws || nranges < 0 || (nranges > 0 && (!offsets || !lengths))) return MMSA_ERR_ARG;
+  return grad_sumsq_ranges(g, (const long*)offsets, (const long*)lengths, nranges, sumsq, ws, (hipStream_t)stream);
+}
+int mmsa_grad_norm_from_sumsq(const double* sumsq, int32_t n, float grad_scale, float max_norm, const float* loss,
+                              int32_t* step_count, float* norm_out, float beta1, float beta2, void* stream) {
+  if (!sumsq || !norm_out) return MMSA_ERR_ARG;
+  return grad_norm_from_sumsq(sumsq, n, grad_scale, max_norm, norm_out, (hipStream_t)stream, loss, step_count, beta1, beta2);
+}
 int mmsa_grad_scale_clip(float* g, int64_t n, const float* norm_clip, void* stream) {
   if (!g || !norm_clip) return MMSA_ERR_ARG;
   return grad_scale_clip(g, n, norm_clip, (hipStream_t)stream);

@@ -113,6 +113,9 @@ extern thread_local int g2_last_plan[3];  // (thread_local: the two encoders may
 #define GEMM_MAX_GROUPS 12  // problems of one grouped weight-gradient launch
 int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st);
 int gemm_bf16_launch_group(const GemmParams* probs, float* const* colsum, int n, hipStream_t st);  // + roofline record
+// streaming kernel for the HBM-bound 1x1 convolutions (gemm_stream.hip); gemm_bf16_launch routes eligible problems to it
+bool gemm_stream_eligible(const GemmParams& p);
+int gemm_stream_launch(const GemmParams& p, hipStream_t st);
 int gemm_f32_launch(const GemmParams& p, hipStream_t st);
 // exact-fp32 GEMM on the matrix cores (gemm_f32_mfma.hip); gemm_f32_launch routes eligible problems to it
 bool gemm_f32_mfma_eligible(const GemmParams& p);

@@ -589,6 +589,11 @@ static int gemm_bf16_launch_inner(const GemmParams& pin, hipStream_t st) {
   if (p.split_k < 1) p.split_k = 1;
   {  // second-generation persistent kernel (gemm_mfma2.hip) for every plain (non-gather) shape it supports
     static const bool v1_only = [] { const char* v = getenv("MMSA_GEMM_V1"); return v && atoi(v) != 0; }();
+    // ... except the HBM-bound 1x1 convolutions of the image encoder's first stages: independent per-wave streams (gemm_stream.hip)
+    if (!v1_only && !use_regstage() && gemm_stream_eligible(p)) {
+      g2_last_plan[0] = 1; g2_last_plan[1] = 0; g2_last_plan[2] = 1;  // (profile tables: tile "64x0" = the streaming kernel)
+      return gemm_stream_launch(p, st);
+    }
     if (!v1_only && !use_regstage() && gemm2_eligible(p)) {
       const size_t avail = p.ws ? (p.ws_bytes > 0 ? (size_t)p.ws_bytes : (size_t)p.split_k * p.M * p.N * sizeof(float)) : 0;
       return gemm2_launch(p, p.split_k > 1 || p.ws_bytes > 0 ? avail : 0, st);

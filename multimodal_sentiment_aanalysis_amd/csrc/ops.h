@@ -123,6 +123,9 @@ int grad_norm(const float* g, long n, float grad_scale, float max_norm, float* n
 int grad_norm_ranges(const float* g, const long* offs, const long* lens, int nr, float grad_scale, float max_norm,
                      float* norm_out, void* ws, hipStream_t st, const float* loss, int* step_count, float b1 = 0.9f,
                      float b2 = 0.999f);
+int grad_sumsq_ranges(const float* g, const long* offs, const long* lens, int nr, double* sumsq, void* ws, hipStream_t st);
+int grad_norm_from_sumsq(const double* sumsq, int n, float grad_scale, float max_norm, float* norm_out, hipStream_t st,
+                         const float* loss, int* step_count, float b1, float b2);
 int grad_scale_clip(float* g, long n, const float* norm_clip, hipStream_t st);
 int adamw_step(float* w, const float* g, float* m, float* v, void* w16, long n, float lr, float b1, float b2, float eps,
                float wd, int step, const float* norm_clip, float grad_scale, hipStream_t st, const int* step_count = nullptr);

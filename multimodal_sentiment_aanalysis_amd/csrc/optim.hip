@@ -84,6 +84,56 @@ int grad_norm_ranges(const float* g, const long* offs, const long* lens, int nr,
   return MMSA_OK;
 }
 
+// The two halves of the norm as separate calls (round 4). (a) sum of squares over ranges, left as ONE double on the device:
+// what a rank of the reduce-scatter step contributes for the gradient shards it owns (the doubles of all ranks are then summed by a
+// one-element all-reduce), or what a gradient range contributes the moment it is announced (its partial sums then run under
+// the rest of the backward instead of behind it). (b) the finalize over n such doubles.
+__global__ __launch_bounds__(256) void grad_sumsq_reduce_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+int grad_sumsq_ranges(const float* g, const long* offs, const long* lens, int nr, double* sumsq, void* ws, hipStream_t st) {
+  if (nr < 0 || nr > 256) return MMSA_ERR_ARG;
+  if (nr == 0) {  // a rank that owns nothing contributes zero
+    if (hipMemsetAsync(sumsq, 0, sizeof(double), st) != hipSuccess) return MMSA_ERR_LAUNCH;
+    return MMSA_OK;
+  }
+  long total = 0;
+  for (int r = 0; r < nr; ++r) {
+    if (lens[r] <= 0 || offs[r] < 0) return MMSA_ERR_ARG;
+    total += lens[r];
+  }
+  int used = 0;
+  for (int r = 0; r < nr; ++r) {
+    long want = (long)((double)SUMSQ_BLOCKS * (double)lens[r] / (double)total);
+    const long cap = (lens[r] / 4 + 255) / 256 + 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    if (used + want > 2 * SUMSQ_BLOCKS) return MMSA_ERR_ARG;
+    hipLaunchKernelGGL(grad_sumsq_partial_kernel, dim3((int)want), dim3(256), 0, st, g + offs[r], lens[r], (double*)ws + used);
+    used += (int)want;
+  }
+  hipLaunchKernelGGL(grad_sumsq_reduce_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, used, sumsq);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+int grad_norm_from_sumsq(const double* sumsq, int n, float grad_scale, float max_norm, float* norm_out, hipStream_t st,
+                         const float* loss, int* step_count, float b1, float b2) {
+  if (n < 1 || n > 2 * SUMSQ_BLOCKS) return MMSA_ERR_ARG;
+  hipLaunchKernelGGL(grad_norm_finalize_kernel, dim3(1), dim3(256), 0, st, sumsq, n, grad_scale, max_norm, loss, step_count,
+                     norm_out, b1, b2);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
 int grad_norm(const float* g, long n, float grad_scale, float max_norm, float* norm_out, void* ws, hipStream_t st,
               const float* loss, int* step_count, float b1, float b2) {
   const int blocks = (int)min((n / 4 + 255) / 256 + 1, (long)SUMSQ_BLOCKS);

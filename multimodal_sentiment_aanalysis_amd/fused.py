@@ -123,6 +123,140 @@ class GradReducer:
             torch.cuda.current_stream(self.flat_g.device).wait_stream(self.stream)
 
 
+class ShardedGradReducer(GradReducer):
+    """The reduce-scatter form of the data-parallel step ("prefer reduce-scatter + all-gather"): every bucket
+    is reduce-SCATTERED instead of all-reduced — rank r ends up with the reduced sum of chunk r of the bucket only — the clip
+    norm is a one-double all-reduce of per-rank partial sums of squares, AdamW steps the owned chunks only (1/world of the 30
+    B/parameter optimizer pass per GPU), and the updated weights are all-GATHERED back (`gather()`): as fp32 master weights
+    (every replica keeps a complete, checkpointable state; same bytes on xGMI as the all-reduce) or as the bf16 working copy the
+    encoders compute with (`gather_dtype="bf16"`: half the gather bytes; the fp32 master of chunks a rank does not own then goes
+    stale until `sync_master()`).
+
+    A bucket [a, b) is cut into world x chunk elements (chunk a multiple of `align`) + a tail of fewer than world x align elements;
+    the tail is all-reduced and stepped by every rank (identical results). The cut depends only on the announced ranges, which a
+    configuration repeats step after step: the layout of the first step is recorded and every later step must reproduce it (the
+    AdamW moments of an element live on the rank that owns it).
+
+    Backends without reduce_scatter_tensor / all_gather_into_tensor (gloo: the world_size-2 CPU tests and the two-ranks-on-one-GPU
+    tests) emulate them with all_reduce / all_gather on the same views, so the bookkeeping is exercised everywhere."""
+
+    def __init__(self, flat_g, bucket_bytes=64 << 20, group=None, min_bucket_bytes=16 << 20, payload="fp32", align=256):
+        super().__init__(flat_g, bucket_bytes, group, min_bucket_bytes, payload)
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.align = int(align)
+        self.native = self.world > 1 and dist.get_backend(group) == "nccl"
+        self.owned, self.tails, self.mains = [], [], []
+        self._layout = None
+
+    def begin_step(self):
+        super().begin_step()
+        self.owned, self.tails, self.mains = [], [], []
+
+    def _cut(self, a, b):
+        n = b - a
+        chunk = (n // (self.world * self.align)) * self.align
+        return chunk, chunk * self.world
+
+    def reduce_range(self, start, length):
+        if self.world == 1 or length <= 0:
+            return
+        ctx = None
+        if self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat_g.device))
+            ctx = torch.cuda.stream(self.stream)
+            ctx.__enter__()
+            self.stream.wait_event(ev)
+        try:
+            for a, b in self.buckets(start, length):
+                chunk, main = self._cut(a, b)
+                if chunk > 0:
+                    self._reduce_scatter(a, chunk, main)
+                    self.owned.append((a + self.rank * chunk, chunk))
+                    self.mains.append((a, main, chunk))
+                if main < b - a:  # the remainder: all-reduced, stepped by every rank
+                    self.works.append(dist.all_reduce(self.flat_g[a + main:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self.tails.append((a + main, b - a - main))
+                self.issued.append((a, b - a))
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+
+    def _reduce_scatter(self, a, chunk, main):
+        view = self.flat_g[a:a + main]
+        own = view[self.rank * chunk:(self.rank + 1) * chunk]
+        if self.payload == "bf16" and self.stream is not None:
+            L = _lib.load()
+            if self._stage is None:
+                self._stage = torch.empty(self.flat_g.numel(), dtype=torch.bfloat16, device=self.flat_g.device)
+            sp = ctypes.c_void_p(self.stream.cuda_stream)
+            sv = self._stage[a:a + main]
+            so = sv[self.rank * chunk:(self.rank + 1) * chunk]
+            check(L.mmsa_cast_f32(_lib.MMSA_BF16, ptr(view), ptr(sv), main, sp), "mmsa_cast_f32")
+            if self.native:
+                dist.reduce_scatter_tensor(so, sv, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                dist.all_reduce(sv, op=dist.ReduceOp.SUM, group=self.group)
+            check(L.mmsa_widen_bf16(ptr(so), ptr(own), chunk, sp), "mmsa_widen_bf16")
+        elif self.native:
+            self.works.append(dist.reduce_scatter_tensor(own, view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:  # emulation: the whole body is reduced; only the owned chunk is used afterwards
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        super().finish()
+        layout = (tuple(self.mains), tuple(self.tails))
+        if self._layout is None:
+            self._layout = layout
+        elif layout != self._layout:
+            raise _lib.MmsaError("ShardedGradReducer: the bucket layout changed between steps (the AdamW moments of an element live "
+                                 "on its owner): rebuild the step after changing which parameters train")
+
+    def step_ranges(self):
+        """Ranges this rank's optimizer steps: its chunks and the replicated tails."""
+        return merge_ranges(self.owned + self.tails)
+
+    def norm_ranges(self):
+        """Ranges whose squares this rank contributes to the global norm: its chunks; the tails are counted once, by rank 0."""
+        return merge_ranges(self.owned + (self.tails if self.rank == 0 else []))
+
+    def gather(self, state, gather_dtype="fp32"):
+        """All-gather the stepped chunks back into every replica (after the optimizer). fp32: the master weights, then a local
+        re-cast of the bf16 working copy of the chunks other ranks stepped. bf16: the working copy itself where a bucket lies wholly
+        inside bf16 engines (the fp32 master of foreign chunks goes stale: sync_master()); fp32 elsewhere (the fusion head computes
+        in fp32 on the master weights)."""
+        if self.world == 1:
+            return
+        L = _lib.load()
+        bf16_spans = merge_ranges([(off, n) for e, off, n in state.ranges if getattr(e, "precision", "fp32") in ("bf16", "fp8")])
+        for a, main, chunk in self.mains:
+            lo = a + self.rank * chunk
+            inside = state.flat_wt is not None and any(s0 <= a and a + main <= s0 + n0 for s0, n0 in bf16_spans)
+            if gather_dtype == "bf16" and inside:
+                self._all_gather(state.flat_wt[a:a + main], chunk)
+                continue
+            self._all_gather(state.flat_w[a:a + main], chunk)
+            if state.flat_wt is not None and state.flat_w.is_cuda:
+                for s0, n0 in ((a, lo - a), (lo + chunk, a + main - lo - chunk)):
+                    if n0 > 0:
+                        check(L.mmsa_cast_f32(_lib.MMSA_BF16, ptr(state.flat_w[s0:s0 + n0]), ptr(state.flat_wt[s0:s0 + n0]), n0,
+                                              stream_ptr()), "mmsa_cast_f32")
+
+    def sync_master(self, state):
+        """bf16 gathers only: bring the fp32 master weights of every replica up to date (before a checkpoint / an evaluation that
+        reads `state_dict()`)."""
+        for a, main, chunk in self.mains:
+            self._all_gather(state.flat_w[a:a + main], chunk)
+
+    def _all_gather(self, view, chunk):
+        own = view[self.rank * chunk:(self.rank + 1) * chunk]
+        if self.native:
+            dist.all_gather_into_tensor(view, own, group=self.group)
+        else:
+            outs = [view[r * chunk:(r + 1) * chunk] for r in range(self.world)]
+            dist.all_gather(outs, own.clone(), group=self.group)
+
+
 class FlatAdamW:
     """clip_grad_norm_(max_norm) + AdamW over a FlatState's buffers (Trainer.py:19-21,80-81) on the HIP kernels.
 
@@ -155,6 +289,9 @@ class FlatAdamW:
         self._set_norm_arrays()
 
     def _set_norm_arrays(self):
+        if len(self.norm_ranges) == 0:  # (a rank of the reduce-scatter step may own nothing of a tiny model)
+            self._offs, self._lens = (ctypes.c_int64 * 1)(0), (ctypes.c_int64 * 1)(0)
+            return
         if len(self.norm_ranges) > 256:
             raise _lib.MmsaError(f"{len(self.norm_ranges)} disjoint gradient ranges in one clip norm (limit 256)")
         self._offs = (ctypes.c_int64 * len(self.norm_ranges))(*[a for a, _ in self.norm_ranges])
@@ -168,18 +305,38 @@ class FlatAdamW:
         self.extra_ranges = subtract_ranges(self.norm_ranges, self.ranges)
         self._set_norm_arrays()
 
+    def set_shard_ranges(self, step_ranges, norm_ranges):
+        """The reduce-scatter step: the ranges this rank steps (its gradient shards + the replicated tails) and the ranges whose
+        squares it contributes to the global norm (its shards; the tails on rank 0 only) are set independently."""
+        self.ranges = merge_ranges(step_ranges)
+        self.norm_ranges = merge_ranges(norm_ranges)
+        self.extra_ranges = []
+        self._set_norm_arrays()
+
     @property
     def t(self):
         """Number of applied steps (host read: a sync; for tests and checkpoints only)."""
         return int(self.steps.item())
 
-    def step(self, grad_scale=1.0, loss=None):
+    def step(self, grad_scale=1.0, loss=None, sumsq_group=None):
+        """sumsq_group (the reduce-scatter step): this rank's norm ranges cover only the gradient shards it owns; the partial sums of
+        squares of all ranks are added by a one-double all-reduce over that process group before the norm is finalized."""
         L = _lib.load()
         st = self.state
-        check(L.mmsa_grad_norm_ranges(ptr(st.flat_g), self._offs, self._lens, len(self.norm_ranges), grad_scale, self.max_norm,
-                                      ptr(loss), ptr(self.steps), ptr(self.norm_out), ptr(self.norm_ws), self.betas[0],
-                                      self.betas[1], stream_ptr()),
-              "mmsa_grad_norm_ranges")
+        if sumsq_group is not None:
+            if getattr(self, "_sumsq", None) is None:
+                self._sumsq = torch.zeros(1, dtype=torch.float64, device=st.flat_g.device)
+            check(L.mmsa_grad_sumsq_ranges(ptr(st.flat_g), self._offs, self._lens, len(self.norm_ranges), ptr(self._sumsq),
+                                           ptr(self.norm_ws), stream_ptr()), "mmsa_grad_sumsq_ranges")
+            dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=None if sumsq_group is True else sumsq_group)
+            check(L.mmsa_grad_norm_from_sumsq(ptr(self._sumsq), 1, grad_scale, self.max_norm, ptr(loss), ptr(self.steps),
+                                              ptr(self.norm_out), self.betas[0], self.betas[1], stream_ptr()),
+                  "mmsa_grad_norm_from_sumsq")
+        else:
+            check(L.mmsa_grad_norm_ranges(ptr(st.flat_g), self._offs, self._lens, len(self.norm_ranges), grad_scale, self.max_norm,
+                                          ptr(loss), ptr(self.steps), ptr(self.norm_out), ptr(self.norm_ws), self.betas[0],
+                                          self.betas[1], stream_ptr()),
+                  "mmsa_grad_norm_ranges")
         for a, n in self.ranges:
             w16 = None if st.flat_wt is None else st.flat_wt[a:a + n]
             check(L.mmsa_adamw_step_dev(ptr(st.flat_w[a:a + n]), ptr(st.flat_g[a:a + n]), ptr(self.m[a:a + n]),
@@ -373,7 +530,8 @@ class FusedTrainStep:
     """model: MultimodalTransformerModel (Trainer contract). One call = one optimizer step."""
 
     def __init__(self, model, device, precision="bf16", lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
-                 max_norm=1.0, bucket_bytes=64 << 20, two_streams=None, min_bucket_bytes=16 << 20, train_mode=True):
+                 max_norm=1.0, bucket_bytes=64 << 20, two_streams=None, min_bucket_bytes=16 << 20, train_mode=True,
+                 shard_optimizer=None, gather_dtype=None):
         """train_mode=False: the forward runs in eval mode (BatchNorm on its running statistics, no dropout) while gradients
         and the optimizer step are still taken — the configuration SURVEY.md section 8(e) prescribes for checking that N ranks x
         B/N samples reproduce one rank x B samples (batch statistics would differ between the two by construction)."""
@@ -395,8 +553,21 @@ class FusedTrainStep:
         # gradient payload of the all-reduce: MMSA_GRAD_PAYLOAD=fp32 | bf16 (default fp32: bit-identical sums on every rank in
         # rank order independent precision; bf16 halves the bytes on xGMI — DESIGN.md §6)
         payload = os.environ.get("MMSA_GRAD_PAYLOAD", "fp32")
-        self.reducer = (GradReducer(self.state.flat_g, bucket_bytes, payload=payload, min_bucket_bytes=min_bucket_bytes)
+        # shard_optimizer (MMSA_SHARD_OPT=1): the reduce-scatter form of the step (ShardedGradReducer): reduce-scatter of every
+        # bucket, one-double all-reduce for the clip norm, AdamW on the owned 1/world of the parameters, all-gather of the updated
+        # weights (gather_dtype / MMSA_GATHER_DTYPE: "fp32" master weights — every replica stays checkpointable — or "bf16": the
+        # encoders' working copy, half the gather bytes, fp32 master of foreign shards stale until sync_master()). Needs every
+        # parameter trainable (the shard layout is cut from the announced ranges).
+        if shard_optimizer is None:
+            shard_optimizer = os.environ.get("MMSA_SHARD_OPT", "0") == "1"
+        self.shard_optimizer = bool(shard_optimizer) and self.world > 1
+        self.gather_dtype = gather_dtype or os.environ.get("MMSA_GATHER_DTYPE", "fp32")
+        if self.shard_optimizer and ranges is not None:
+            raise _lib.MmsaError("shard_optimizer needs every parameter trainable (frozen sub-graphs: use the all-reduce step)")
+        rcls = ShardedGradReducer if self.shard_optimizer else GradReducer
+        self.reducer = (rcls(self.state.flat_g, bucket_bytes, payload=payload, min_bucket_bytes=min_bucket_bytes)
                         if self.world > 1 else None)
+        self.exposed_events = None  # bench.py: [(before, after)] timing events around the join with the collective stream
         if self.world > 1:  # identical replicas: parameters and BN buffers from rank 0
             dist.broadcast(self.state.flat_w, 0)
             dist.broadcast(self.state.flat_bn, 0)
@@ -416,11 +587,6 @@ class FusedTrainStep:
         # ms/step on the same box; MMSA_WGRAD_STREAM=0 turns it off; ignored by the engine under data parallelism
         if self._image_net is not None and self.device.type == "cuda" and os.environ.get("MMSA_WGRAD_STREAM", "1") != "0":
             self._image_net.use_wgrad_stream(True)
-        # optional: the two cross-modal transformers on side streams beside the fusion chain (MMSA_HEAD_STREAMS=1; A/B hook)
-        self._head_streams = None
-        if os.environ.get("MMSA_HEAD_STREAMS", "0") == "1" and hasattr(model, "use_head_streams") and self.device.type == "cuda":
-            model.use_head_streams(True)
-            self._head_streams = model._head_streams
         self._ranges = {id(e): (off, n) for e, off, n in self.state.ranges}
         for e, off, n in self.state.ranges:
             on = self.reducer is not None
@@ -450,7 +616,7 @@ class FusedTrainStep:
             # loudly instead (tools/microbench/graph_probe.py captures the single-stream step; a graph buys nothing here: the step
             # is GPU-bound, DESIGN.md section 3 "Host side").
             side = getattr(self._image_net, "_side", None) is not None or getattr(self._image_net, "_wgrad_stream", None) is not None
-            if side or self._head_streams is not None or self.reducer is not None:
+            if side or self.reducer is not None:
                 raise _lib.MmsaError("FusedTrainStep.step cannot be stream-captured with its side streams on: build it with "
                                      "two_streams=False and MMSA_WGRAD_STREAM=0 (single process) to capture the step")
         model.train(self.train_mode)
@@ -466,15 +632,29 @@ class FusedTrainStep:
         logits.backward(dlogits)
         if self._image_net is not None:
             self._image_net.join()
-        if self._head_streams is not None:  # their backward kernels wrote parameter gradients autograd does not track
-            for st in self._head_streams:
-                torch.cuda.current_stream(self.device).wait_stream(st)
         if self.reducer is not None:
-            self.reducer.finish()
+            if self.exposed_events is not None:  # how long the step waits for the collectives the backward did not hide
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.reducer.finish()
+                e1.record()
+                self.exposed_events.append((e0, e1))
+            else:
+                self.reducer.finish()
         # NaN rule (Trainer.py:74-76): decided on the device from the reduced gradient norm (identical on every rank, so
         # the replicas stay in step); a NaN loss on any rank makes its gradients, hence the reduced norm, non-finite
-        self.opt.step(1.0 / self.world, self.loss if self.world == 1 else None)
+        if self.shard_optimizer:
+            self.opt.set_shard_ranges(self.reducer.step_ranges(), self.reducer.norm_ranges())
+            self.opt.step(1.0 / self.world, None, sumsq_group=True)
+            self.reducer.gather(self.state, self.gather_dtype)
+        else:
+            self.opt.step(1.0 / self.world, self.loss if self.world == 1 else None)
         return self.loss, logits
+
+    def sync_master(self):
+        """After steps with gather_dtype="bf16": all-gather the fp32 master weights (before state_dict() / a checkpoint)."""
+        if self.shard_optimizer and self.gather_dtype == "bf16":
+            self.reducer.sync_master(self.state)
 
     @property
     def lr(self):

@@ -162,3 +162,91 @@ def test_global_negatives_gradient_equals_single_process(tmp_path):
     assert torch.allclose(r0["loss"], loss.detach(), atol=1e-6) and torch.allclose(r1["loss"], loss.detach(), atol=1e-6)
     assert torch.allclose(r0["gw"], w.grad, atol=1e-6, rtol=1e-5), (r0["gw"] - w.grad).abs().max()
     assert torch.equal(r0["gw"], r1["gw"])
+
+
+def _shard_worker(rank, world, port, out):
+    """The reduce-scatter form (fused.ShardedGradReducer) on CPU tensors over gloo: the same announcements as the all-reduce
+    path; afterwards every rank holds the reduced gradient exactly on the ranges it owns (chunks + replicated tails), the owned
+    ranges of the two ranks tile every announced element, a torch stand-in of the optimizer applied to the owned ranges only
+    plus the all-gather reproduces the all-reduce path's weights bit for bit on BOTH ranks, and the partial sums of squares of
+    the norm ranges add up to the squared norm of the whole reduced gradient (tails counted once)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodal_sentiment_aanalysis_amd.fused import GradReducer, ShardedGradReducer
+
+    class State:  # the two attributes gather() touches on a CPU state: fp32 master, no bf16 copy
+        ranges = []
+        flat_wt = None
+
+    n = 70_000
+    announce = [(40_000, 29_000), (39_000, 1_000), (20_100, 18_900), (3_000, 9_037)]  # uneven, one not a multiple of anything
+    torch.manual_seed(7 + rank)
+    g_local = torch.randn(n)
+    torch.manual_seed(99)
+    w0 = torch.randn(n)
+    # reference: all-reduce path, every rank steps everything it reduced
+    g_ref = g_local.clone()
+    ref = GradReducer(g_ref, bucket_bytes=16 << 10, min_bucket_bytes=8 << 10)
+    ref.begin_step()
+    for a, ln in announce:
+        ref.add(a, ln)
+    ref.finish()
+    touched = torch.zeros(n, dtype=torch.bool)
+    for a, ln in ref.issued:
+        touched[a:a + ln] = True
+    w_ref = torch.where(touched, w0 - 0.1 * g_ref / world, w0)
+    # reduce-scatter path
+    g = g_local.clone()
+    red = ShardedGradReducer(g, bucket_bytes=16 << 10, min_bucket_bytes=8 << 10, align=64)
+    for step in range(2):  # the second step must reproduce the first step's layout
+        g.copy_(g_local)
+        red.begin_step()
+        for a, ln in announce:
+            red.add(a, ln)
+        red.finish()
+    own = torch.zeros(n, dtype=torch.int32)
+    for a, ln in red.step_ranges():
+        own[a:a + ln] += 1
+        assert torch.equal(g[a:a + ln], g_ref[a:a + ln]), "owned range does not hold the reduced gradient"
+    assert int(own.max()) == 1
+    cover = [torch.zeros(n, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(cover, own)
+    tails = torch.zeros(n, dtype=torch.bool)
+    for a, ln in red.tails:
+        tails[a:a + ln] = True
+    total = sum(cover)
+    assert torch.equal(total[touched & ~tails], torch.ones_like(total[touched & ~tails])), "every chunk has exactly one owner"
+    assert torch.equal(total[tails], torch.full_like(total[tails], world)), "tails are stepped by every rank"
+    assert int(total[~touched].sum()) == 0
+    assert any(ln > 0 for _, ln in red.owned) and len(red.mains) >= 4
+    # norm: partial sums of squares over the norm ranges add up to the whole reduced gradient's
+    part = torch.zeros(1, dtype=torch.float64)
+    for a, ln in red.norm_ranges():
+        part += g[a:a + ln].double().pow(2).sum()
+    dist.all_reduce(part)
+    want = g_ref[touched].double().pow(2).sum()
+    assert abs(part.item() - want.item()) <= 1e-9 * want.item()
+    # "optimizer" on the owned ranges only, then the all-gather
+    st = State()
+    st.flat_w = w0.clone()
+    for a, ln in red.step_ranges():
+        st.flat_w[a:a + ln] -= 0.1 * g[a:a + ln] / world
+    red.gather(st, "fp32")
+    assert torch.equal(st.flat_w, w_ref), "reduce-scatter + owned step + all-gather != all-reduce + full step"
+    # a different announcement pattern afterwards is refused (the moments of an element live on its owner)
+    red.begin_step()
+    red.add(3_000, 5_000)
+    try:
+        red.finish()
+        raised = False
+    except Exception as e:  # MmsaError
+        raised = "layout" in str(e)
+    assert raised
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_step_bookkeeping_matches_all_reduce(tmp_path):
+    port = _free_port()
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

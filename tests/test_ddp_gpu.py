@@ -55,9 +55,9 @@ def _batch(dev):
     return synth_batch(16, 32, 64, 64, MINI_BERT["vocab"], seed=11, dev=dev)
 
 
-def _run_step(model, dev, sl, **kw):
+def _run_step(model, dev, sl, precision="fp32", **kw):
     from multimodal_sentiment_aanalysis_amd.fused import FusedTrainStep
-    step = FusedTrainStep(model, dev, precision="fp32", train_mode=False, min_bucket_bytes=64 << 10, **kw)
+    step = FusedTrainStep(model, dev, precision=precision, train_mode=False, min_bucket_bytes=64 << 10, **kw)
     w0 = step.state.flat_w.clone()
     image, ids, mask, labels = _batch(dev)
     counts = []
@@ -83,11 +83,21 @@ def _worker(rank, world, port, out, case):
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     model, frozen = _build(seed=rank, freeze=(case == "frozen"))  # rank 1 starts from OTHER weights: rank 0's are broadcast
-    step, w0, loss, counts = _run_step(model, dev, slice(rank * 8, rank * 8 + 8))
+    kw = {}
+    if case.startswith("shard"):  # the reduce-scatter form of the step (fused.ShardedGradReducer)
+        kw = dict(shard_optimizer=True, gather_dtype="bf16" if case == "shard_bf16" else "fp32")
+    precision = "bf16" if case in ("shard_bf16", "ar_bf16") else "fp32"
+    step, w0, loss, counts = _run_step(model, dev, slice(rank * 8, rank * 8 + 8), precision=precision, **kw)
+    wt_before_sync = None if step.state.flat_wt is None else step.state.flat_wt.float().cpu()
+    w_before_sync = step.state.flat_w.cpu()
+    step.sync_master()
+    torch.cuda.synchronize()
     names = {n: (p.data_ptr() - step.state.flat_w.data_ptr()) // 4 for n, p in model.named_parameters()
              if 0 <= (p.data_ptr() - step.state.flat_w.data_ptr()) // 4 < step.state.flat_w.numel()}
     torch.save(dict(g=step.state.flat_g.cpu(), w=step.state.flat_w.cpu(), w0=w0.cpu(), loss=loss, counts=counts,
                     issued=list(step.reducer.issued), norm=step.opt.norm_out.cpu(), frozen=frozen, offs=names,
+                    wt=wt_before_sync, w_stale=w_before_sync, owned=list(getattr(step.reducer, "owned", [])),
+                    tails=list(getattr(step.reducer, "tails", [])),
                     numel={n: p.numel() for n, p in model.named_parameters()}),
                os.path.join(out, f"r{rank}.pt"))
     dist.barrier()
@@ -161,3 +171,62 @@ def test_two_ranks_partially_frozen_encoder(dev, tmp_path):
     one = _single(dev, freeze=True)
     err = (0.5 * r0["g"] - one["g"]).abs().max().item() / one["g"].abs().max().item()
     assert err < 1e-5, err
+
+
+def test_two_ranks_reduce_scatter_step_equals_the_all_reduce_step(dev, tmp_path):
+    """SURVEY.md section 8(e)'s preferred collective shape (reduce-scatter + all-gather) as a switch of the same step
+    (FusedTrainStep(shard_optimizer=True) / MMSA_SHARD_OPT=1): every bucket reduce-scattered, the clip norm from a one-double
+    all-reduce of per-rank partial sums of squares, AdamW on the owned chunks only, fp32 master weights all-gathered. Two real
+    processes on cuda:0: replicas bit-identical, and bit-identical to the all-reduce form of the step on the same two ranks."""
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    a0, a1 = _spawn(tmp_path / "a", "fp32")
+    s0, s1 = _spawn(tmp_path / "b", "shard")
+    assert torch.equal(s0["w"], s1["w"]), "replicas diverged after reduce-scatter + sharded AdamW + all-gather"
+    assert torch.equal(s0["w0"], a0["w0"])
+    assert abs(s0["norm"][0] - a0["norm"][0]).item() <= 1e-6 * a0["norm"][0].item(), (s0["norm"], a0["norm"])
+    assert torch.equal(s0["norm"], s1["norm"]), "every rank must take the same clip / skip decision"
+    if not torch.equal(s0["w"], a0["w"]):  # diagnostics: which elements, by how much, and where they live
+        bad = (s0["w"] != a0["w"])
+        where = torch.zeros(s0["w"].numel(), dtype=torch.int32)
+        for a, n in s0["owned"]:
+            where[a:a + n] |= 1
+        for a, n in s1["owned"]:
+            where[a:a + n] |= 2
+        for a, n in s0["tails"]:
+            where[a:a + n] |= 4
+        idx = bad.nonzero().flatten()
+        print("differing elements:", int(bad.sum()), "of", bad.numel(), "first", idx[:5].tolist(), "last", idx[-5:].tolist(),
+              "max |diff|", (s0["w"] - a0["w"]).abs().max().item(),
+              "by place (0 unannounced, 1 rank0 chunk, 2 rank1 chunk, 4 tail):", torch.bincount(where[bad], minlength=8).tolist(),
+              "norms", s0["norm"].tolist(), a0["norm"].tolist(), "g equal on owned:",
+              all(torch.equal(s0["g"][a:a + n], a0["g"][a:a + n]) for a, n in s0["owned"]))
+    assert torch.equal(s0["w"], a0["w"]), "the reduce-scatter step must reproduce the all-reduce step's weights bit for bit"
+    # each rank stepped only its own chunks (+ the replicated tails): the two ranks' chunks are disjoint and non-empty
+    own0 = torch.zeros(s0["w"].numel(), dtype=torch.int32)
+    for r in (s0, s1):
+        assert r["owned"], "a rank owns nothing"
+        for a, n in r["owned"]:
+            own0[a:a + n] += 1
+    assert int(own0.max()) == 1
+    covered = torch.zeros_like(own0)
+    for a, n in s0["issued"]:
+        covered[a:a + n] += 1
+    tails = torch.zeros_like(own0)
+    for a, n in s0["tails"]:
+        tails[a:a + n] += 1
+    assert torch.equal((covered > 0), ((own0 + tails) > 0)), "chunks + tails tile exactly what was announced"
+
+
+def test_two_ranks_reduce_scatter_step_bf16_gather(dev, tmp_path):
+    """The same with the encoders in bf16 and the bf16 WORKING COPY all-gathered (half the gather bytes): the working copies of
+    the two replicas are bit-identical to each other and to the all-reduce step's; the fp32 master of the chunks a rank does not
+    own is stale until sync_master(), after which it equals the all-reduce step's master bit for bit."""
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    a0, a1 = _spawn(tmp_path / "a", "ar_bf16")
+    s0, s1 = _spawn(tmp_path / "b", "shard_bf16")
+    assert torch.equal(s0["wt"], s1["wt"]), "bf16 working copies of the replicas differ"
+    assert torch.equal(s0["wt"], a0["wt"]), "bf16 working copy differs from the all-reduce step's"
+    assert not torch.equal(s0["w_stale"], s1["w_stale"]), "before sync_master() each rank holds only its own chunks' master"
+    assert torch.equal(s0["w"], s1["w"]) and torch.equal(s0["w"], a0["w"]), "fp32 master after sync_master()"
