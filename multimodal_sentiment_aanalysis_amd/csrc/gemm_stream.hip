@@ -20,7 +20,7 @@
 //          tiles, one 16-lane DPP reduction per kernel, waves combined through LDS: ONE partial row per workgroup
 //          (256-512 rows for the finalize instead of M / 64 = 3136)
 //   EPI 2  + add[M][N] (the skip connection's gradient in a 1x1 data gradient): the side operand's 16-byte loads are issued before
-//          the tile's MFMAs; the sum is taken in fp32 (four fp32 lane swaps per tile pair), rounded once
+//          the tile's MFMAs and lane-swapped into the accumulator layout; the sum is taken in fp32, rounded once
 // Reference slot: the encoder position of MML_ZYC/MultimodalModel.py:264-266 (ResNet-50 is not in the reference).
 #include <mutex>
 #include "gemm.h"
@@ -127,17 +127,22 @@ __global__ __launch_bounds__(GS_THREADS) void gemm_stream_kernel(GsParams p) {
     for (int jp = 0; jp < NT / 2; ++jp) {
       const f32x4 x = acc[2 * jp], y = acc[2 * jp + 1];
       if constexpr (EPI == 2) {
-        f32x4 lo, hi;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const auto s = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x[r]), __builtin_bit_cast(unsigned, y[r]), false, false);
-          lo[r] = __builtin_bit_cast(float, s[0]);
-          hi[r] = __builtin_bit_cast(float, s[1]);
-        }
-        const bf16x8 sv = side[jp];
-        const bf16x8 o = {(bf16)(lo[0] + (float)sv[0]), (bf16)(lo[1] + (float)sv[1]), (bf16)(lo[2] + (float)sv[2]), (bf16)(lo[3] + (float)sv[3]),
-                          (bf16)(hi[0] + (float)sv[4]), (bf16)(hi[1] + (float)sv[5]), (bf16)(hi[2] + (float)sv[6]), (bf16)(hi[3] + (float)sv[7])};
-        *(bf16x8*)(cr + jp * 32) = o;
+        // The side operand was loaded in the STORE layout (8 consecutive columns per lane); the lane swap is an involution, so
+        // the same two swaps bring it into the accumulator layout (4 columns of tile 2jp and of tile 2jp + 1 per lane); the sum is
+        // taken there in fp32 and rounded once, then stored like the plain form. (Swapping the fp32 accumulators instead — four
+        // v_permlane16_swap in a loop over the register index — was miscompiled by hipcc 7.2: one swap per pair survived.)
+        const gs_i32x4 sv = __builtin_bit_cast(gs_i32x4, side[jp]);
+        const auto t0 = __builtin_amdgcn_permlane16_swap((unsigned)sv[0], (unsigned)sv[2], false, false);
+        const auto t1 = __builtin_amdgcn_permlane16_swap((unsigned)sv[1], (unsigned)sv[3], false, false);
+        const gs_i32x2 sxi = {(int)t0[0], (int)t1[0]}, syi = {(int)t0[1], (int)t1[1]};
+        const bf16x4 sx = __builtin_bit_cast(bf16x4, sxi), sy = __builtin_bit_cast(bf16x4, syi);
+        const bf16x4 xb = {(bf16)(x[0] + (float)sx[0]), (bf16)(x[1] + (float)sx[1]), (bf16)(x[2] + (float)sx[2]), (bf16)(x[3] + (float)sx[3])};
+        const bf16x4 yb = {(bf16)(y[0] + (float)sy[0]), (bf16)(y[1] + (float)sy[1]), (bf16)(y[2] + (float)sy[2]), (bf16)(y[3] + (float)sy[3])};
+        const gs_i32x2 xi = __builtin_bit_cast(gs_i32x2, xb), yi = __builtin_bit_cast(gs_i32x2, yb);
+        const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)xi[0], (unsigned)yi[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)xi[1], (unsigned)yi[1], false, false);
+        const gs_i32x4 d = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+        *(gs_i32x4*)(cr + jp * 32) = d;
       } else {
         const bf16x4 xb = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
         const bf16x4 yb = {(bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
@@ -203,6 +208,189 @@ __global__ __launch_bounds__(GS_THREADS) void gemm_stream_kernel(GsParams p) {
   if (stamped) stamp_end(p.stamp);
 }
 
+// ---- 3 x 3 convolutions of stage 1 (64 -> 64 channels, stride 1) as streams ----------------------------------------------------
+// The same structure for the implicit-GEMM 3 x 3 convolution with 64 input and 64 output channels (forward: conv2 of the three
+// stage-1 bottlenecks; data gradient: the same geometry with flipped taps): K = 9 taps x 64, N = 64. On the persistent kernel
+// these are 9-step tiles whose step time does not depend on the tile width (latency-bound: ~1.2 us per K step): 42 us = 350
+// TFLOP/s for 14.8 GFLOP and 51 MB. Here all nine 64 x 64 weight blocks sit in LDS (74 KiB forward, 144 KiB k-major for the data
+// gradient), a wave owns 16 consecutive output pixels and fetches, per tap row ky, the three shifted 16-pixel windows straight from
+// global memory (each input pixel is one 128-byte line: the 9-fold re-reads are L1 / L2 hits of lines the neighbouring taps and
+// waves already touched; padding taps are dropped by the buffer descriptor and read zeros); the three tap rows of the NEXT tile are
+// requested as soon as the current tile has consumed theirs. K order = tap-major, as the persistent kernel: bit-identical results.
+struct Gs3Params {
+  const bf16* A; const bf16* B; bf16* C;
+  int M, ntiles;
+  long ldb, ldc;
+  long tap_off[9];   // element offset of tap (ky, kx) inside a B row (forward: tap * 64; data gradient: b_tap_offset)
+  unsigned a_bytes;
+  ConvGeom g;
+  float* colstat;
+  unsigned long long* stamp;
+};
+
+template <bool B_KM, int EPI>
+__global__ __launch_bounds__(GS_THREADS) void gemm_stream3x3_kernel(Gs3Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NT = 4, C = 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const bool stamped = (blockIdx.x & 7) == 0 || blockIdx.x == gridDim.x - 1;
+  if (stamped) stamp_begin(p.stamp);
+  // weight blocks, one per tap: forward [64 n][64 k] k-contiguous (8 KiB each), data gradient [64 k][128 (64 used) n] k-major (16 KiB)
+  if constexpr (!B_KM) {
+    for (int c = tid; c < 9 * 64 * 8; c += GS_THREADS) {
+      const int tap = c >> 9, row = (c >> 3) & 63, kc = c & 7;
+      *(bf16x8*)(smem + tap * 8192 + kc_off(row, kc)) = *(const bf16x8*)(p.B + (long)row * p.ldb + p.tap_off[tap] + kc * 8);
+    }
+  } else {
+    for (int c = tid; c < 9 * 64 * 8; c += GS_THREADS) {
+      const int tap = c >> 9, k = (c >> 3) & 63, nc = c & 7;
+      *(bf16x8*)(smem + tap * 16384 + km_off(k, nc)) = *(const bf16x8*)(p.B + (long)k * p.ldb + p.tap_off[tap] + nc * 8);
+    }
+  }
+  __syncthreads();
+  // A workgroup owns a CONTIGUOUS run of tiles and deals them to its waves round robin (128 consecutive pixels per step: the
+  // neighbouring image rows its taps reach are the lines the same CU touched a step earlier — L1 / L2 hits). Dealing tiles across
+  // the whole grid, as the 1 x 1 streams do, made every tap a miss in the XCD's 4 MiB L2 (each XCD walked the whole 25.7 MB input):
+  // 462 MB of L2 fills per launch served by the Infinity Cache — 37 us instead of ~15.
+  const int per_wg = (p.ntiles + gridDim.x - 1) / gridDim.x;
+  const int t_end = min(p.ntiles, (int)(blockIdx.x + 1) * per_wg);
+  const int rw = blockIdx.x * per_wg + wave, nrw = 8;
+  __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  constexpr int OOB = (int)0x80000000;
+  unsigned opaque = 0;
+
+  // the three shifted windows of tap row ky for the tile whose lane pixel is px: 3 taps x 2 k-halves x 16 bytes per lane. The
+  // geometry is stride 1 (div == 1, checked by the launcher): the source pixel of tap (ky, kx) is the lane's own base pixel plus a
+  // per-tap constant, and only the two range checks are per lane (gemm_tile.h's general tap_src carries the strided / divided
+  // forms as divergent branches: 150 instructions per tap, which made the first version of this kernel slower than the GEMM).
+  const int kmul = p.g.kmul, SH = p.g.SH, SW = p.g.SW;
+  auto load_row = [&](bf16x8 (&a)[6], const RowPix& px, int ky) __attribute__((always_inline)) {
+    const int sy = px.yb + ky * kmul;
+    const bool yok = px.img >= 0 && (unsigned)sy < (unsigned)SH;
+    const int rowbase = ((px.img * SH + sy) * SW + px.xb) * C + 8 * g4;  // element offset of (img, sy, xb) + this lane's k chunk
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int sx = px.xb + kx * kmul;
+      const bool ok = yok && (unsigned)sx < (unsigned)SW;
+      const int vo = ok ? (rowbase + kx * kmul * C) * 2 : OOB;
+      a[2 * kx] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, vo, 0, 0));
+      a[2 * kx + 1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, vo, 64, 0));
+    }
+  };
+  f32x4 acc[NT];
+  // the 8 weight fragments of one tap (2 k-halves x 4 column tiles), read one tap AHEAD of the MFMAs that use them: left to itself
+  // hipcc reads each fragment right before its MFMA (lgkmcnt(1) chains), and a wave then waits an LDS round trip (~100 cycles
+  // under load) per 16-cycle MFMA — the first version of this kernel ran at 400 TFLOP/s for that reason
+  auto read_tap = [&](bf16x8 (&b)[8], int tap) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if constexpr (!B_KM) b[kk * NT + j] = read_frag<false>(smem + opaque + tap * 8192, j * 16, kk, lane);
+        else b[kk * NT + j] = read_frag<true>(smem + tap * 16384, j * 16, kk, lane);
+      }
+  };
+  auto mma_tap = [&](const bf16x8 (&b)[8], const bf16x8 (&a)[6], int kx) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[kk * NT + j], a[2 * kx + kk], acc[j], 0, 0, 0);
+  };
+  bf16x8 bq0[8], bq1[8];
+  // tap row ky with its fragments double-buffered: on entry bq0 holds tap 3 ky; on exit bq0 holds tap 3 ky + 3 (when there is one)
+  auto mma_row = [&](const bf16x8 (&a)[6], int ky) __attribute__((always_inline)) {
+    read_tap(bq1, 3 * ky + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tap(bq0, a, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_tap(bq0, 3 * ky + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tap(bq1, a, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_tap(bq1, ky < 2 ? 3 * ky + 3 : 0);  // (after the last row: tap 0 again, for the next tile)
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tap(bq0, a, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bq0[i] = bq1[i];
+  };
+  f32x4 cs[EPI == 1 ? NT : 1], cq[EPI == 1 ? NT : 1];
+  if constexpr (EPI == 1) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+
+  bf16x8 a0[6], a1[6], a2[6];
+  int t = rw;
+  if (t < t_end) {
+    const RowPix px = decompose_pixel(p.g, t * 16 + r16, p.M);
+    load_row(a0, px, 0); load_row(a1, px, 1); load_row(a2, px, 2);
+  }
+  read_tap(bq0, 0);
+  for (; t < t_end; t += nrw) {
+    if constexpr (!B_KM) asm volatile("" : "+v"(opaque));  // (keeps the weight-fragment reads inside the loop: see gemm_stream_kernel)
+    const int tn = t + nrw;
+    const bool more = tn < t_end;
+    RowPix pn;
+    if (more) pn = decompose_pixel(p.g, tn * 16 + r16, p.M);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_row(a0, 0);
+    if (more) load_row(a0, pn, 0);
+    mma_row(a1, 1);
+    if (more) load_row(a1, pn, 1);
+    mma_row(a2, 2);
+    if (more) load_row(a2, pn, 2);
+    // epilogue: as gemm_stream_kernel (lane = one pixel, 8 consecutive channels after the lane swap)
+    const int m = t * 16 + r16;
+    const int col_in_pair = (g4 & 1) * 16 + ((g4 >> 1) << 3);
+    bf16* cr = p.C + (long)m * p.ldc + col_in_pair;
+#pragma unroll
+    for (int jp = 0; jp < NT / 2; ++jp) {
+      const f32x4 x = acc[2 * jp], y = acc[2 * jp + 1];
+      const bf16x4 xb = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
+      const bf16x4 yb = {(bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
+      if constexpr (EPI == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float qx = (float)xb[r], qy = (float)yb[r];
+          cs[2 * jp][r] += qx; cq[2 * jp][r] += qx * qx;
+          cs[2 * jp + 1][r] += qy; cq[2 * jp + 1][r] += qy * qy;
+        }
+      }
+      const gs_i32x2 xi = __builtin_bit_cast(gs_i32x2, xb), yi = __builtin_bit_cast(gs_i32x2, yb);
+      const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)xi[0], (unsigned)yi[0], false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)xi[1], (unsigned)yi[1], false, false);
+      const gs_i32x4 d = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+      *(gs_i32x4*)(cr + jp * 32) = d;
+    }
+  }
+  if constexpr (EPI == 1) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { cs[j][r] = gs_row16_sum(cs[j][r]); cq[j][r] = gs_row16_sum(cq[j][r]); }
+    __syncthreads();
+    float* red = (float*)smem;  // [8 waves][2][64]
+    if (r16 == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = j * 16 + 4 * g4;
+        *(f32x4*)(red + ((long)wave * 2 + 0) * C + n) = cs[j];
+        *(f32x4*)(red + ((long)wave * 2 + 1) * C + n) = cq[j];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * C; i += GS_THREADS) {
+      float sum = 0.f;
+      for (int w = 0; w < 8; ++w) sum += red[(long)w * 2 * C + i];
+      p.colstat[(long)blockIdx.x * 2 * C + i] = sum;
+    }
+  }
+  if (stamped) stamp_end(p.stamp);
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------
 static int gs_cus() {
   static int n = 0;
@@ -224,18 +412,39 @@ static size_t gs_lds_bytes(const GemmParams& p) {
 // Which problems take this kernel: plain (no gather, no row map, no K split) bf16 NT / NN problems with K in {64, 128, 256},
 // N in {64, 128, 256, 512}, N · K <= 65536 (the weight image fits 128 KiB of LDS), M a multiple of 16 and >= 4096 rows, epilogue = plain store (+ statistics) or + add. MMSA_DISABLE=stream1x1 turns
 // it off (A/B and parity switch: the persistent kernel then takes these launches as before).
+// the 3 x 3 form: gather = 1 with a 3 x 3 stride-1 geometry over 64 channels, 64 output channels, plain store (+ statistics)
+static bool gs3_eligible(const GemmParams& p) {
+  if (mmsa_disabled("stream3x3") || getenv("MMSA_G2_NJ")) return false;
+  if (p.gather != 1 || p.a_kmajor || p.c_gw > 0 || p.split_k > 1 || p.scale_a || p.out_f32) return false;
+  if (p.bias || p.C2 || p.mul || p.add || p.act != MMSA_ACT_NONE || p.act_after_add) return false;
+  if (p.N != 64 || p.K != 576 || p.g.cper != 64 || p.g.KH != 3 || p.g.KW != 3 || p.g.div != 1 || p.g.src_pix_stride != 64) return false;
+  if (p.M < 4096 || (p.M % 16) || (p.ldc % 8) || (p.ldb % 8)) return false;
+  if (p.colstat && (p.b_kmajor || !p.colstat_rows || p.colstat_cap < (long)2 * 1024 * p.N)) return false;
+  const long ghw = (long)p.g.GH * p.g.GW;
+  if (ghw <= 0 || (p.M % ghw)) return false;
+  const long ea = (p.M / ghw) * p.g.SH * p.g.SW * p.g.src_pix_stride * 2;
+  if (ea >= 0x7FFFFFF0L) return false;
+  return true;
+}
+
 bool gemm_stream_eligible(const GemmParams& p) {
+  if (gs3_eligible(p)) return true;
   if (mmsa_disabled("stream1x1") || getenv("MMSA_G2_NJ")) return false;  // (a forced tile shape addresses the persistent kernel)
   if (p.gather || p.a_kmajor || p.c_gw > 0 || p.split_k > 1 || p.scale_a || p.out_f32) return false;
   if (p.bias || p.C2 || p.mul || p.act != MMSA_ACT_NONE || p.act_after_add) return false;
   if (p.add && p.colstat) return false;
   if (p.M < 4096 || (p.M % 16)) return false;
-  if (!(p.K == 64 || p.K == 128 || p.K == 256)) return false;  // (K = 512 streams at 4.1-4.5 TB/s on the persistent kernel already)
+  // (K = 512 streams at 4.1-4.5 TB/s on the persistent kernel already; K = 192 = the stem's padded im2col matrix, N = 64)
+  if (!(p.K == 64 || p.K == 128 || p.K == 256 || (p.K == 192 && p.N == 64))) return false;
   if (!(p.N == 64 || p.N == 128 || p.N == 256 || p.N == 512)) return false;
   if ((long)p.N * p.K > 65536 || (p.N == 256 && p.K == 256)) return false;
   if ((p.lda % 8) || (p.ldb % 8) || (p.ldc % 8) || (p.add && (p.ldadd % 8))) return false;
   if (((long)p.M * p.lda) >= 0x3FFFFFFFL * 2 || ((long)p.M * p.ldc) >= 0x3FFFFFFFL * 2) return false;
   if (p.colstat && (!p.colstat_rows || p.colstat_cap < (long)2 * 1024 * p.N)) return false;  // (room for up to 1024 partial rows)
+  // with the statistics a wave keeps 16 more registers per column tile: measured on MI355X (profiles/r04_*) the stream wins for the
+  // narrow outputs and for N = 256 at K = 64 (25.6 against 31.2 us) and loses where the columns must be split over 2-4 wave groups
+  // that each re-read A (N = 512: 24.6 against 22.6 us) or the register budget halves the occupancy (N = 128, K = 256: 41.9 / 40.6)
+  if (p.colstat && !(p.N == 64 || (p.N == 256 && p.K == 64) || (p.N == 128 && p.K <= 128))) return false;
   return true;
 }
 
@@ -288,12 +497,61 @@ static int gs_launch_n(const GsParams& gp, const GemmParams& p, size_t lds, hipS
   switch (p.K / 32) {
     case 2: return gs_launch_nk<NT, 2>(gp, p, lds, st);
     case 4: return gs_launch_nk<NT, 4>(gp, p, lds, st);
+    case 6:  // K = 192: the stem convolution's zero-padded 7 x 7 x 3 = 147 im2col columns (N = 64 only)
+      if constexpr (NT == 4) return gs_launch_nk<NT, 6>(gp, p, lds, st);
+      else return MMSA_ERR_UNSUPPORTED;
     case 8: return gs_launch_nk<NT, 8>(gp, p, lds, st);
     default: return MMSA_ERR_UNSUPPORTED;
   }
 }
 
+template <bool B_KM, int EPI>
+static int gs3_launch_t(const Gs3Params& gp, size_t lds, int* rows_out, hipStream_t st) {
+  static int occ = 0;
+  static std::mutex mu;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!occ) {
+      (void)hipFuncSetAttribute((const void*)gemm_stream3x3_kernel<B_KM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      int o = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)gemm_stream3x3_kernel<B_KM, EPI>, GS_THREADS, lds) != hipSuccess || o < 1) o = 1;
+      occ = o > 2 ? 2 : o;  // (74 KiB of weights: up to two workgroups per CU; 144 KiB: one) — every workgroup of the grid must be resident
+    }
+  }
+  int grid = gs_cus() * occ;
+  if ((long)grid * 8 > gp.ntiles) grid = (gp.ntiles + 7) / 8;
+  if (rows_out) *rows_out = grid;
+  hipLaunchKernelGGL((gemm_stream3x3_kernel<B_KM, EPI>), dim3(grid), dim3(GS_THREADS), lds, st, gp);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+
+static int gs3_launch(const GemmParams& p, hipStream_t st) {
+  if (p.colstat_rows) *p.colstat_rows = 0;
+  Gs3Params gp;
+  gp.A = (const bf16*)p.A; gp.B = (const bf16*)p.B; gp.C = (bf16*)p.C;
+  gp.M = p.M; gp.ntiles = p.M / 16; gp.ldb = p.ldb; gp.ldc = p.ldc;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) gp.tap_off[ky * 3 + kx] = p.b_kmajor ? b_tap_offset(p, ky, kx) : (long)(ky * 3 + kx) * 64;
+  gp.a_bytes = (unsigned)((p.M / ((long)p.g.GH * p.g.GW)) * p.g.SH * p.g.SW * p.g.src_pix_stride * 2);
+  gp.g = p.g;
+  gp.colstat = p.colstat;
+  gp.stamp = p.stamp;
+  if (!p.b_kmajor) {
+    const size_t lds = 9 * 8192;
+    if (p.colstat) {
+      int rows = 0;
+      const int rc = gs3_launch_t<false, 1>(gp, lds, &rows, st);
+      if (rc == MMSA_OK) *p.colstat_rows = rows;
+      return rc;
+    }
+    return gs3_launch_t<false, 0>(gp, lds, nullptr, st);
+  }
+  return gs3_launch_t<true, 0>(gp, 9 * 16384, nullptr, st);
+}
+
 int gemm_stream_launch(const GemmParams& p, hipStream_t st) {
+  if (gs3_eligible(p)) return gs3_launch(p, st);
   if (!gemm_stream_eligible(p)) return MMSA_ERR_UNSUPPORTED;
   if (p.colstat_rows) *p.colstat_rows = 0;
   GsParams gp;

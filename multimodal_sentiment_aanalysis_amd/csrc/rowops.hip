@@ -231,6 +231,225 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
+// ---- bf16 rows of 768 / 1024 elements: half a wave per row, 16-byte accesses (round 4) -----------------------------------------
+// A 768-element bf16 row is 1536 bytes = 32 lanes x 3 chunks of 16 bytes: each half of a wave takes one row (a wave-instruction
+// then moves 1 KiB — two 512-byte row segments — instead of 512 bytes with the 8-byte accesses of the general kernels above, which
+// streamed at 2.9-3.2 TB/s at 8192 x 768), row statistics are 32-lane reductions (5 xor steps), and the loads of the wave's NEXT
+// row pair are in flight while the current one is reduced. Same expressions as the general kernels, another summation order.
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ void unpack8(bf16x8 t, float (&f)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (float)t[e];
+}
+
+template <int NC>  // H = 256 NC
+__global__ __launch_bounds__(256) void layernorm_fwd_hw_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, bf16* __restrict__ y,
+                                                               float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                               int M, float eps, unsigned char* __restrict__ q_out,
+                                                               float* __restrict__ q_scales) {
+  constexpr int H = 256 * NC;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane & 31, half = lane >> 5;
+  const int npairs = (M + 1) >> 1, stride = gridDim.x * 4;
+  int pr = blockIdx.x * 4 + w;
+  if (pr >= npairs) return;
+  float g[NC][8], b[NC][8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = (h + 32 * c) * 8;
+    const f32x4 g0 = *(const f32x4*)(gamma + col), g1 = *(const f32x4*)(gamma + col + 4);
+    const f32x4 b0 = *(const f32x4*)(beta + col), b1 = *(const f32x4*)(beta + col + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g[c][e] = g0[e]; g[c][4 + e] = g1[e]; b[c][e] = b0[e]; b[c][4 + e] = b1[e]; }
+  }
+  bf16x8 cur[NC], nxt[NC];
+  auto load = [&](bf16x8 (&t)[NC], int pair) __attribute__((always_inline)) {
+    const int row = min(2 * pair + half, M - 1);  // (the odd last row: the idle half re-reads it, nothing is stored)
+    const bf16* xr = x + (long)row * H + h * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) t[c] = *(const bf16x8*)(xr + 256 * c);
+  };
+  load(cur, pr);
+  for (; pr < npairs; pr += stride) {
+    const bool more = pr + stride < npairs;
+    if (more) load(nxt, pr + stride);
+    const int row = 2 * pr + half;
+    const bool live = row < M;
+    float v[NC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      unpack8(cur[c], v[c]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[c][e];
+    }
+    const float mean = half_sum(s) * (1.0f / (float)H);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
+    const float rstd = rsqrtf(half_sum(q) * (1.0f / (float)H) + eps);
+    if (h == 0 && live) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+    bf16* yr = y + (long)row * H + h * 8;
+    float am = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = (bf16)((v[c][e] - mean) * rstd * g[c][e] + b[c][e]);
+        v[c][e] = (float)o[e];  // the value as stored (the fp8 image below quantizes what the bf16 consumers see)
+        const float a = fabsf(v[c][e]);
+        bad |= !(a <= 3.0e38f);
+        am = fmaxf(am, a);
+      }
+      if (live) *(bf16x8*)(yr + 256 * c) = o;
+    }
+    if (q_out) {  // fp8 mode: the row's e4m3 image with its own scale (layernorm_fwd_kernel's arithmetic)
+      if (bad) am = __builtin_inff();
+      am = fmaxf(half_max(am), 1e-20f);
+      const float inv = 448.0f / am;
+      if (h == 0 && live) q_scales[row] = am * (1.0f / 448.0f);
+      unsigned char* qr = q_out + (long)row * H + h * 8;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(v[c][e] * inv, -448.0f), 448.0f);
+        int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+        p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], p0, true);
+        int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+        p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], p1, true);
+        if (live) *(int2*)(qr + 256 * c) = make_int2(p0, p1);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) cur[c] = nxt[c];
+    }
+  }
+}
+
+// backward of the same rows: dx and the per-workgroup partials of dgamma / dbeta (/ column sums of the stored dx) in the layout of
+// layernorm_bwd_kernel ([blk][NQ][H]; the finalize launch is shared)
+template <int NC>
+__global__ __launch_bounds__(512) void layernorm_bwd_hw_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, bf16* __restrict__ dx,
+                                                               float* __restrict__ part, int M, int NQ) {
+  constexpr int H = 256 * NC;
+  extern __shared__ float lds[];  // [NW waves][H], reused per quantity
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6, h = lane & 31, half = lane >> 5;
+  const int npairs = (M + 1) >> 1, stride = gridDim.x * NW;
+  float g[NC][8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = (h + 32 * c) * 8;
+    const f32x4 g0 = *(const f32x4*)(gamma + col), g1 = *(const f32x4*)(gamma + col + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g[c][e] = g0[e]; g[c][4 + e] = g1[e]; }
+  }
+  float ag[NC][8], ab[NC][8], ax[NC][8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; ax[c][e] = 0.f; }
+  bf16x8 cx[NC], cd[NC], nx[NC], nd[NC];
+  auto load = [&](bf16x8 (&tx)[NC], bf16x8 (&td)[NC], int pair) __attribute__((always_inline)) {
+    const int row = min(2 * pair + half, M - 1);
+    const bf16* xr = x + (long)row * H + h * 8;
+    const bf16* dr = dy + (long)row * H + h * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { tx[c] = *(const bf16x8*)(xr + 256 * c); td[c] = *(const bf16x8*)(dr + 256 * c); }
+  };
+  int pr = blockIdx.x * NW + w;
+  if (pr < npairs) load(cx, cd, pr);
+  for (; pr < npairs; pr += stride) {
+    const bool more = pr + stride < npairs;
+    if (more) load(nx, nd, pr + stride);
+    const int row = 2 * pr + half;
+    const bool live = row < M;
+    const int rc = min(row, M - 1);
+    const float mu = mean[rc], rs = rstd[rc];
+    const float lv = live ? 1.f : 0.f;  // the idle half of an odd last pair contributes zeros
+    float xh[NC][8], gg[NC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float xv[8], dv[8];
+      unpack8(cx[c], xv);
+      unpack8(cd[c], dv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dvl = dv[e] * lv;
+        xh[c][e] = (xv[e] - mu) * rs;
+        gg[c][e] = dvl * g[c][e];
+        s1 += gg[c][e];
+        s2 += gg[c][e] * xh[c][e];
+        ag[c][e] += dvl * xh[c][e];
+        ab[c][e] += dvl;
+      }
+    }
+    s1 = half_sum(s1) * (1.0f / (float)H);
+    s2 = half_sum(s2) * (1.0f / (float)H);
+    bf16* oxr = dx + (long)row * H + h * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = (bf16)(rs * (gg[c][e] - s1 - xh[c][e] * s2));
+        ax[c][e] += (float)o[e] * lv;  // the value as stored (what a column sum over dx would read)
+      }
+      if (live) *(bf16x8*)(oxr + 256 * c) = o;
+    }
+    if (more) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { cx[c] = nx[c]; cd[c] = nd[c]; }
+    }
+  }
+  // the two halves of a wave hold the same columns (other rows): add them, then combine the waves through LDS as the general kernel
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ag[c][e] += __shfl_xor(ag[c][e], 32, 64);
+      ab[c][e] += __shfl_xor(ab[c][e], 32, 64);
+      ax[c][e] += __shfl_xor(ax[c][e], 32, 64);
+    }
+  for (int qn = 0; qn < NQ; ++qn) {
+    if (half == 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float* dst = lds + w * H + (h + 32 * c) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[e] = qn == 0 ? ag[c][e] : (qn == 1 ? ab[c][e] : ax[c][e]);
+      }
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += blockDim.x) {
+      float t = 0.f;
+      for (int ww = 0; ww < NW; ++ww) t += lds[ww * H + col];
+      part[((long)blockIdx.x * NQ + qn) * H + col] = t;
+    }
+    __syncthreads();
+  }
+}
+
 // out_q[j] (+)= sum_b part[(b * nq + q) * n + j] for q < nq (up to 3 outputs in one launch; fixed order as below)
 __global__ __launch_bounds__(256) void partial_finalize_multi_kernel(const float* __restrict__ part, int nblk, int nq, int n,
                                                                      float* __restrict__ out0, float* __restrict__ out1,
@@ -297,6 +516,18 @@ int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* bet
                   int M, int H, float eps, hipStream_t st, void* q_out, float* q_scales) {
   if (H % 4 || H > 2048) return MMSA_ERR_ARG;
   if (q_out && (dtype != MMSA_BF16 || !q_scales)) return MMSA_ERR_ARG;
+  // bf16 rows of 768 / 1024 elements: the half-wave kernel (16-byte accesses, next row pair prefetched); MMSA_DISABLE=ln_halfwave
+  if (dtype == MMSA_BF16 && (H == 768 || H == 1024) && M >= 64 && !mmsa_disabled("ln_halfwave")) {
+    const int gridh = min(cdiv(cdiv(M, 2), 4), 1024);
+    if (H == 768)
+      hipLaunchKernelGGL(layernorm_fwd_hw_kernel<3>, dim3(gridh), dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M,
+                         eps, (unsigned char*)q_out, q_scales);
+    else
+      hipLaunchKernelGGL(layernorm_fwd_hw_kernel<4>, dim3(gridh), dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M,
+                         eps, (unsigned char*)q_out, q_scales);
+    MMSA_CHECK_LAUNCH();
+    return MMSA_OK;
+  }
   const int grid = min(cdiv(M, 4), 4096);
   if (dtype == MMSA_BF16)
     LN_DISPATCH(layernorm_fwd_kernel, bf16, H, dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, mean,
@@ -323,6 +554,18 @@ int layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, c
   const int grid = min(cdiv(M, nw), LN_BWD_BLOCKS);
   const size_t lds = (size_t)nw * H * sizeof(float);
   const int nq = dxsum ? 3 : 2;
+  // (H = 768 only: at 1024 the three accumulator sets + two row pairs of raw data exceed 256 registers)
+  if (dtype == MMSA_BF16 && H == 768 && M >= 64 && !mmsa_disabled("ln_halfwave")) {
+    const int gridh = min(cdiv(cdiv(M, 2), nw), LN_BWD_BLOCKS);
+    hipLaunchKernelGGL(layernorm_bwd_hw_kernel<3>, dim3(gridh), dim3(64 * nw), lds, st, (const bf16*)dy, (const bf16*)x, mean, rstd,
+                       gamma, (bf16*)dx, ws, M, nq);
+    MMSA_CHECK_LAUNCH();
+    if (!dgamma && !dbeta && !dxsum) return MMSA_OK;
+    hipLaunchKernelGGL(partial_finalize_multi_kernel, dim3(cdiv(nq * H, 16)), dim3(256), 0, st, (const float*)ws, gridh, nq, H,
+                       dgamma, dbeta, dxsum, accumulate);
+    MMSA_CHECK_LAUNCH();
+    return MMSA_OK;
+  }
   if (dtype == MMSA_BF16)
     LN_DISPATCH(layernorm_bwd_kernel, bf16, H, dim3(grid), dim3(64 * nw), lds, st, (const bf16*)dy, (const bf16*)x, mean, rstd,
                 gamma, (bf16*)dx, ws, M, H, nq);

@@ -80,3 +80,40 @@ def test_stream_respects_leading_dimensions(dev):
     err = (C.float() - ref).abs().max().item() / ref.abs().max().item()
     assert err < 1.2e-2, err
     assert Cbig[:, :64].abs().max().item() == 0 and Cbig[:, 64 + N:].abs().max().item() == 0, "stores stay inside the view"
+
+
+@pytest.mark.parametrize("B,H,W", [(32, 56, 56), (8, 40, 24), (16, 33, 17)])
+def test_stream_3x3_stage1_matches_conv2d_and_persistent_kernel(dev, B, H, W):
+    """The 3 x 3 stream (64 -> 64 channels, stride 1, pad 1: conv2 of the stage-1 bottlenecks, forward and data gradient)
+    against F.conv2d + autograd and, bit for bit, against the persistent kernel's implicit GEMM (same tap-major K order). Odd
+    image sizes make 16-pixel tiles straddle image rows and images (every lane decomposes its own pixel; padding taps read
+    zeros through the buffer descriptor)."""
+    import torch.nn.functional as F
+    if (B * H * W) % 16 or B * H * W < 4096:
+        pytest.skip("not a stream shape")
+    Cin = Cout = 64
+    x = rnd((B, H, W, Cin), dev, 1)
+    w = rnd((Cout, 3, 3, Cin), dev, 2, 0.1)
+    dy = rnd((B, H, W, Cout), dev, 3)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.float().permute(0, 3, 1, 2)
+    yr = F.conv2d(xr, wr, stride=1, padding=1)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    M, Kd = B * H * W, 9 * Cin
+    res = {}
+    for tag, off in (("stream", None), ("persistent", "stream3x3")):
+        ctx = disabled(off) if off else disabled("")
+        with ctx:
+            y = torch.full((M, Cout), float("nan"), dtype=BF, device=dev)
+            g = K.conv_geom(H, W, H, W, 3, 3, 1, 1, -1, 1, Cin, Cin)
+            K.gemm(x, w, y, M, Cout, Kd, Cin, Kd, Cout, gather=1, geom=g, impl=GEMM_BF16_MFMA)
+            dx = torch.full((M, Cin), float("nan"), dtype=BF, device=dev)
+            g = K.conv_geom(H, W, H, W, 3, 3, 1, -1, 1, 1, Cout, Cout)
+            K.gemm(dy, w, dx, M, Cin, 9 * Cout, Cout, Kd, Cin, b_kmajor=1, gather=1, geom=g, b_tap_stride=Cin, impl=GEMM_BF16_MFMA)
+        res[tag] = (y, dx)
+    y, dx = res["stream"]
+    e1 = (y.view(B, H, W, Cout).float() - yr.detach().permute(0, 2, 3, 1)).abs().max().item() / yr.abs().max().item()
+    e2 = (dx.view(B, H, W, Cin).float() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() / xr.grad.abs().max().item()
+    assert e1 < 1.2e-2 and e2 < 1.2e-2, (e1, e2)
+    assert torch.equal(y, res["persistent"][0]), "forward differs from the persistent kernel"
+    assert torch.equal(dx, res["persistent"][1]), "data gradient differs from the persistent kernel"

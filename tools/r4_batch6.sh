@@ -1,0 +1,10 @@
+#!/bin/bash
+# round-4 batch 6: stream parity tests, engine tests; A/B of the 3x3 stream; fp32 per-shape table
+set -o pipefail
+O=gpurun_out/r4h
+mkdir -p $O
+python -m pytest tests/test_gemm_stream_gpu.py -x -q > $O/tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/tests.log
+for v in stream3x3 ""; do
+  MMSA_DISABLE=$v MMSA_PROF_DUMP=$O/shapes_${v:-on}.csv python3 bench.py --no-cpu-baseline --repeats 3 --exact-steps 0 > $O/ab_${v:-on}.json 2>> $O/ab.err
+  python3 -c "import json,sys;d=json.loads(open('$O/ab_${v:-on}.json').read().strip().splitlines()[-1]);print('disable=[$v]',d['protocol']['ms_per_step_by_region'],d['roofline']['kernel_ms_per_step'],d['roofline']['isolated']['kernel_ms_per_step'], d['forward']['ms'])"
+done
