@@ -85,6 +85,9 @@ struct BertWs {
   float *q_wscales, *q_rowscales, *q_batchws;  // per-tensor weight scales [4 * layers], per-token scales [B*S], quantizer scratch
   size_t colws_bytes;
   float *splitk, *colws, *lnws, *attnws;
+  // deferred finalizes (round 4): every LayerNorm backward of the step keeps its own partial buffer and every layer its own bias
+  // scratch until ONE batched finalize / pick launch per announced range (bwd: lnws_l[2 l], [2 l + 1], [2 layers] = embeddings)
+  std::vector<float*> lnws_l, colws_l;
   size_t splitk_bytes;
   size_t total;
 };
@@ -141,6 +144,8 @@ static BertWs bert_ws(const mmsa_bert_cfg& c, void* base) {
     w.q_batchws = (float*)b.take(fp8_quantize_batch_ws_bytes(FP8_BATCH_MAX));
   }
   w.lnws = (float*)b.take(layernorm_bwd_ws_bytes((int)H));
+  for (int l = 0; l < 2 * c.layers + 1; ++l) w.lnws_l.push_back((float*)b.take(layernorm_bwd_ws_bytes((int)H)));
+  for (int l = 0; l < c.layers; ++l) w.colws_l.push_back((float*)b.take(colb));
   w.attnws = (float*)b.take(attention_bwd_ws_bytes(c.batch, c.seq, c.heads));
   w.total = b.off;
   return w;
@@ -321,6 +326,22 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
   }
   if (lowest == nl) return MMSA_OK;  // every encoder layer and the embeddings are frozen: the backward ends here
   void *dOut = ws.bufA, *bC = ws.bufC;
+  // The finalizes of the LayerNorm parameter gradients and the picks of the grouped bias gradients feed nothing but the optimizer:
+  // they are recorded and flushed as ONE launch each per announced range (every `layers_per_chunk` layers under data parallelism,
+  // once per backward otherwise) instead of 37 launches of ~6 us between the GEMMs of this serial chain. MMSA_DISABLE=defer_finalize
+  // launches them in place (A/B and parity switch: same kernels bodies, bit-identical gradients).
+  const bool deferf = !mmsa_disabled("defer_finalize");
+  std::vector<LnFinJob> ln_jobs;
+  std::vector<BiasPickJob> pick_jobs;
+  if (deferf) e.defer_picks = &pick_jobs;
+  auto ln_defer = [&](LnFinJob& j) { if (j.part) ln_jobs.push_back(j); };
+  auto flush_deferred = [&]() -> int {
+    if (!ln_jobs.empty()) RET_IF(layernorm_bwd_finalize_batch(ln_jobs.data(), (int)ln_jobs.size(), H, st));
+    if (!pick_jobs.empty()) RET_IF(bias_pick_batch(pick_jobs.data(), (int)pick_jobs.size(), st));
+    ln_jobs.clear();
+    pick_jobs.clear();
+    return MMSA_OK;
+  };
   if (hipMemsetAsync(dOut, 0, (size_t)M * H * es, st) != hipSuccess) return MMSA_ERR_LAUNCH;
   RET_IF(e.linear_dgrad(ws.dprepool, H, W(lay.wp), dOut, (long)S * H, B, H, H));  // only the [CLS] rows receive gradient
   long chunk_end = lay.wp;  // encoder layers [l, ...) up to chunk_end are complete but not yet announced
@@ -336,16 +357,20 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
     // (a wholly frozen layer produces NO parameter gradient: its LayerNorm / bias gradient outputs are null, so that stale
     //  gradients of an earlier phase stay what torch would keep and a data-parallel replica never steps an un-reduced range)
     const bool lf = layer_frozen[l];
+    LnFinJob lj;
     RET_IF(layernorm_bwd(sdt(c), dOut, a.s2, a.mean2, a.rstd2, P(f.ln2w), ds2, lf ? nullptr : G(f.ln2w),
-                         lf ? nullptr : G(f.ln2b), acc, ws.lnws, M, H, st, lf ? nullptr : G(f.b2)));
+                         lf ? nullptr : G(f.ln2b), acc, deferf ? ws.lnws_l[2 * l] : ws.lnws, M, H, st, lf ? nullptr : G(f.b2),
+                         deferf ? &lj : nullptr));
+    if (deferf) ln_defer(lj);
     void* dpre = ws.bufI;
     RET_IF(e.linear_dgrad(ds2, H, W(f.w2), dpre, I, M, H, I, a.pre, I, nullptr, 0, gelu_factor()));  // * gelu'(pre), stored by the forward
     void* dh1 = bC;
     RET_IF(e.linear_dgrad(dpre, I, W(f.w1), dh1, H, M, I, H, nullptr, 0, ds2, H));  // + residual branch
     void* ds1 = ws.bufS;  // (its own buffer: dOut / bC rotate under it and the grouped weight gradients read it last)
     RET_IF(layernorm_bwd(sdt(c), dh1, a.s1, a.mean1, a.rstd1, P(f.ln1w), ds1, lf ? nullptr : G(f.ln1w),
-                         lf ? nullptr : G(f.ln1b), acc, ws.lnws, M, H, st,
-                         lf ? nullptr : G(f.bo)));  // + bias gradient of the attention output Linear
+                         lf ? nullptr : G(f.ln1b), acc, deferf ? ws.lnws_l[2 * l + 1] : ws.lnws, M, H, st,
+                         lf ? nullptr : G(f.bo), deferf ? &lj : nullptr));  // + bias gradient of the attention output Linear
+    if (deferf) ln_defer(lj);
     void* dctx = ws.bufD;
     RET_IF(e.linear_dgrad(ds1, H, W(f.wo), dctx, H, M, H, H));
     void* dqkv = ws.bufQ;
@@ -363,25 +388,36 @@ int mmsa_bert_bwd_cb(const mmsa_bert_cfg* cp, const float* w32, const void* wt, 
           {ds1, H, a.ctx, H, G(f.wo), nullptr, H, H},
           {dqkv, 3L * H, xin, H, G(f.wqkv), G(f.bqkv), 3 * H, H},
       };
+      if (deferf) e.col_ws = ws.colws_l[l];  // (this layer's bias results stay put until the flush)
       RET_IF(e.wgrad_group(jobs, 4, M, acc));
+      e.col_ws = ws.colws;
     }
     // rotate: dx becomes the next layer's dOut
     void* t = dOut; dOut = bC; bC = t;
     if ((c.layers - l) % layers_per_chunk == 0 || l == 0 || last_needed) {
-      if (cb && chunk_live) cb(user, f.wqkv, chunk_end - f.wqkv);
+      if (cb && chunk_live) {
+        RET_IF(flush_deferred());  // an announced range is complete
+        cb(user, f.wqkv, chunk_end - f.wqkv);
+      }
       chunk_end = f.wqkv;
       chunk_live = false;
     }
   }
-  if (lowest >= 0) return MMSA_OK;  // the embeddings are frozen
+  if (lowest >= 0) return flush_deferred();  // the embeddings are frozen
   // embeddings
   void* de = ws.bufB;
-  RET_IF(layernorm_bwd(sdt(c), dOut, ws.e, ws.mean0, ws.rstd0, P(lay.lnw), de, G(lay.lnw), G(lay.lnb), acc, ws.lnws, M, H, st));
+  {
+    LnFinJob lj;
+    RET_IF(layernorm_bwd(sdt(c), dOut, ws.e, ws.mean0, ws.rstd0, P(lay.lnw), de, G(lay.lnw), G(lay.lnb), acc,
+                         deferf ? ws.lnws_l[2 * c.layers] : ws.lnws, M, H, st, nullptr, deferf ? &lj : nullptr));
+    if (deferf) ln_defer(lj);
+  }
   if (!acc && c.type_vocab > 1 &&
       hipMemsetAsync(G(lay.type) + H, 0, (size_t)(c.type_vocab - 1) * H * sizeof(float), st) != hipSuccess)
     return MMSA_ERR_LAUNCH;
   RET_IF(embed_backward(sdt(c), (const long long*)ids, de, G(lay.word), G(lay.pos), G(lay.type), acc, ws.colws, B, S, H,
                         c.vocab, c.max_pos, st));
+  RET_IF(flush_deferred());
   if (cb) cb(user, 0, lay.L[0].wqkv);
   return MMSA_OK;
 }

@@ -63,6 +63,9 @@ struct Eng {
   float* col_ws;  // colsum partials
   size_t col_ws_bytes = 0;      // capacity of col_ws (0: unknown, bias problems are not grouped)
   const void* ones8 = nullptr;  // optional [rows][8] bf16 ones (rows >= the M of wgrad_group): bias gradients ride in the group
+  // optional: the picks of the grouped bias gradients are recorded here instead of launched (the caller then owns col_ws until
+  // it flushes them with bias_pick_batch: one launch for a whole backward instead of one per layer)
+  std::vector<BiasPickJob>* defer_picks = nullptr;
 
   size_t esz() const { return dtype == MMSA_BF16 ? 2 : 4; }
   // MMSA_BF16_SIMT=1 (diagnostic): run the bf16 path on the SIMT kernels — same storage rounding, independent code —
@@ -231,7 +234,9 @@ struct Eng {
       if (rc == MMSA_ERR_UNSUPPORTED && nb > 0) rc = gemm_bf16_launch_group(ps, cs, n, st);  // without the bias problems
       if (rc != MMSA_ERR_UNSUPPORTED) {
         if (rc) return rc;
-        if (biases_in_group)
+        if (biases_in_group && defer_picks) {
+          for (int b = 0; b < nb; ++b) defer_picks->push_back(BiasPickJob{col_ws + scratch_off[b], jobs[bias_of[b]].db, jobs[bias_of[b]].N});
+        } else if (biases_in_group)
           RET_IF(bias_pick(col_ws + scratch_off[0], jobs[bias_of[0]].db, jobs[bias_of[0]].N,
                            nb > 1 ? col_ws + scratch_off[1] : nullptr, nb > 1 ? jobs[bias_of[1]].db : nullptr,
                            nb > 1 ? jobs[bias_of[1]].N : 0, st));

@@ -23,9 +23,14 @@ int partial_finalize(const float* part, int nblk, long stride, int n, float* out
 int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                   int M, int H, float eps, hipStream_t st, void* q_out = nullptr, float* q_scales = nullptr);
 size_t layernorm_bwd_ws_bytes(int H);
+// deferred finalize of a LayerNorm backward (rowops.hip): what layernorm_bwd records instead of launching it when `defer` is given
+struct LnFinJob { const float* part; int nblk, nq, accumulate; float *out0, *out1, *out2; };
+#define LN_FIN_MAX 32
+struct LnFinBatch { int H; LnFinJob job[LN_FIN_MAX]; };
 int layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                   void* dx, float* dgamma, float* dbeta, int accumulate, float* ws, int M, int H, hipStream_t st,
-                  float* dxsum = nullptr);
+                  float* dxsum = nullptr, LnFinJob* defer = nullptr);
+int layernorm_bwd_finalize_batch(const LnFinJob* jobs, int n, int H, hipStream_t st);
 size_t colsum_ws_bytes(int N);
 int colsum(int dtype, const void* x, long ldx, float* out, int accumulate, float* ws, int M, int N, hipStream_t st);
 int embed_gather(int dtype, const long long* ids, const void* word, const void* pos, const void* type, void* e, int M,
@@ -43,6 +48,10 @@ int tanh_bwd(int dtype, const void* dy, const void* y, void* dx, long n, hipStre
 
 // dst[i] = src[8 i] for one or two (src, dst, n) pairs: picks the bias gradients out of the grouped launch's [N][8] results
 int bias_pick(const float* src, float* dst, int n, const float* src2, float* dst2, int n2, hipStream_t st);
+struct BiasPickJob { const float* src; float* dst; int n; };
+#define BIAS_PICK_MAX 32
+struct BiasPickBatch { BiasPickJob job[BIAS_PICK_MAX]; };
+int bias_pick_batch(const BiasPickJob* jobs, int n, hipStream_t st);
 int fill_ones_bf16(void* dst, long n, hipStream_t st);
 
 // contrastive.hip (N1)

@@ -546,10 +546,48 @@ int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* bet
 size_t layernorm_bwd_ws_bytes(int H) { return (size_t)LN_BWD_BLOCKS * 3 * H * sizeof(float); }
 
 // dxsum (optional): column sums of the stored dx (+)= -> the bias gradient of the Linear that produced this LN's input
+// Batched finalize of deferred LayerNorm backwards (round 4): the parameter gradients of a LayerNorm (and the bias gradient that
+// rides along) are needed only by the optimizer, but their finalize was a 6 us launch between two GEMMs of the text encoder's serial
+// backward chain, 25 times a step. With `defer` set, layernorm_bwd launches the row kernel only — into a partial buffer of the
+// CALLER'S that stays untouched until the flush — and records the finalize as a job; layernorm_bwd_finalize_batch runs up to
+// LN_FIN_MAX jobs as ONE launch (blockIdx.y = job). Same kernel body, same summation order: bit-identical gradients.
+__global__ __launch_bounds__(256) void partial_finalize_batch_kernel(LnFinBatch b) {
+  __shared__ float red[16][17];
+  const LnFinJob j = b.job[blockIdx.y];
+  const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int jj = blockIdx.x * 16 + c;
+  const int n = b.H, nq = j.nq;
+  float t = 0.f;
+  if (jj < nq * n)
+    for (int k = r; k < j.nblk; k += 16) t += j.part[(long)k * nq * n + jj];
+  red[r][c] = t;
+  __syncthreads();
+  if (r != 0 || jj >= nq * n) return;
+  t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t += red[k][c];
+  const int q = jj / n, col = jj - q * n;
+  float* out = q == 0 ? j.out0 : (q == 1 ? j.out1 : j.out2);
+  if (!out) return;
+  out[col] = j.accumulate ? out[col] + t : t;
+}
+int layernorm_bwd_finalize_batch(const LnFinJob* jobs, int n, int H, hipStream_t st) {
+  for (int i = 0; i < n; i += LN_FIN_MAX) {
+    LnFinBatch b;
+    b.H = H;
+    const int m = n - i < LN_FIN_MAX ? n - i : LN_FIN_MAX;
+    for (int k = 0; k < m; ++k) b.job[k] = jobs[i + k];
+    hipLaunchKernelGGL(partial_finalize_batch_kernel, dim3(cdiv(3 * H, 16), m), dim3(256), 0, st, b);
+    MMSA_CHECK_LAUNCH();
+  }
+  return MMSA_OK;
+}
+
 int layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                   void* dx, float* dgamma, float* dbeta, int accumulate, float* ws, int M, int H, hipStream_t st,
-                  float* dxsum) {
+                  float* dxsum, LnFinJob* defer) {
   if (H % 4 || H > 2048) return MMSA_ERR_UNSUPPORTED;
+  if (defer) defer->part = nullptr;
   const int nw = H > 1024 ? 4 : LN_BWD_WAVES;
   const int grid = min(cdiv(M, nw), LN_BWD_BLOCKS);
   const size_t lds = (size_t)nw * H * sizeof(float);
@@ -561,6 +599,7 @@ int layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, c
                        gamma, (bf16*)dx, ws, M, nq);
     MMSA_CHECK_LAUNCH();
     if (!dgamma && !dbeta && !dxsum) return MMSA_OK;
+    if (defer) { *defer = LnFinJob{ws, gridh, nq, accumulate, dgamma, dbeta, dxsum}; return MMSA_OK; }
     hipLaunchKernelGGL(partial_finalize_multi_kernel, dim3(cdiv(nq * H, 16)), dim3(256), 0, st, (const float*)ws, gridh, nq, H,
                        dgamma, dbeta, dxsum, accumulate);
     MMSA_CHECK_LAUNCH();
@@ -574,6 +613,7 @@ int layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, c
                 rstd, gamma, (float*)dx, ws, M, H, nq);
   MMSA_CHECK_LAUNCH();
   if (!dgamma && !dbeta && !dxsum) return MMSA_OK;  // wholly frozen layer: only dx was wanted
+  if (defer) { *defer = LnFinJob{ws, grid, nq, accumulate, dgamma, dbeta, dxsum}; return MMSA_OK; }
   // partial layout is [blk][nq][H]: one launch finalizes every output (null = that parameter is frozen)
   hipLaunchKernelGGL(partial_finalize_multi_kernel, dim3(cdiv(nq * H, 16)), dim3(256), 0, st, (const float*)ws, grid, nq, H,
                      dgamma, dbeta, dxsum, accumulate);
@@ -774,6 +814,22 @@ int bias_pick(const float* src, float* dst, int n, const float* src2, float* dst
   if (n <= 0 || n2 < 0) return MMSA_ERR_ARG;
   hipLaunchKernelGGL(bias_pick_kernel, dim3(cdiv(n + n2, 256)), dim3(256), 0, st, src, dst, n, src2, dst2, n2);
   MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
+}
+// the same for up to BIAS_PICK_MAX deferred (src, dst, n) triples in one launch (a BERT backward's 24 grouped bias gradients)
+__global__ __launch_bounds__(256) void bias_pick_batch_kernel(BiasPickBatch b) {
+  const BiasPickJob j = b.job[blockIdx.y];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < j.n; i += gridDim.x * 256) j.dst[i] = j.src[(long)i * 8];
+}
+int bias_pick_batch(const BiasPickJob* jobs, int n, hipStream_t st) {
+  for (int i = 0; i < n; i += BIAS_PICK_MAX) {
+    BiasPickBatch b;
+    const int m = n - i < BIAS_PICK_MAX ? n - i : BIAS_PICK_MAX;
+    int nmax = 1;
+    for (int k = 0; k < m; ++k) { b.job[k] = jobs[i + k]; nmax = jobs[i + k].n > nmax ? jobs[i + k].n : nmax; }
+    hipLaunchKernelGGL(bias_pick_batch_kernel, dim3(cdiv(nmax, 256), m), dim3(256), 0, st, b);
+    MMSA_CHECK_LAUNCH();
+  }
   return MMSA_OK;
 }
 int fill_ones_bf16(void* dst, long n, hipStream_t st) {

@@ -318,18 +318,12 @@ class FlatAdamW:
         """Number of applied steps (host read: a sync; for tests and checkpoints only)."""
         return int(self.steps.item())
 
-    def step(self, grad_scale=1.0, loss=None, sumsq_group=None, presummed=None):
+    def step(self, grad_scale=1.0, loss=None, sumsq_group=None):
         """sumsq_group (the reduce-scatter step): this rank's norm ranges cover only the gradient shards it owns; the partial sums of
-        squares of all ranks are added by a one-double all-reduce over that process group before the norm is finalized.
-        presummed = (device float64 tensor, n): the sums of squares of ranges that tile the norm ranges exactly were already taken
-        (FusedTrainStep takes them as the backward announces each range): only the finalize runs here."""
+        squares of all ranks are added by a one-double all-reduce over that process group before the norm is finalized."""
         L = _lib.load()
         st = self.state
-        if presummed is not None:
-            check(L.mmsa_grad_norm_from_sumsq(ptr(presummed[0]), int(presummed[1]), grad_scale, self.max_norm, ptr(loss),
-                                              ptr(self.steps), ptr(self.norm_out), self.betas[0], self.betas[1], stream_ptr()),
-                  "mmsa_grad_norm_from_sumsq")
-        elif sumsq_group is not None:
+        if sumsq_group is not None:
             if getattr(self, "_sumsq", None) is None:
                 self._sumsq = torch.zeros(1, dtype=torch.float64, device=st.flat_g.device)
             check(L.mmsa_grad_sumsq_ranges(ptr(st.flat_g), self._offs, self._lens, len(self.norm_ranges), ptr(self._sumsq),
@@ -594,50 +588,13 @@ class FusedTrainStep:
         if self._image_net is not None and self.device.type == "cuda" and os.environ.get("MMSA_WGRAD_STREAM", "1") != "0":
             self._image_net.use_wgrad_stream(True)
         self._ranges = {id(e): (off, n) for e, off, n in self.state.ranges}
-        # Single process: the sum of squares of each gradient range is taken the moment the backward announces it (on the stream
-        # that produced it, under the backward of the layers below) instead of in one 540 MB pass behind the whole backward: after
-        # the join only the finalize and AdamW remain in the step's serial tail. Needs every parameter trainable (the announced
-        # ranges then tile the buffer); MMSA_EARLY_SUMSQ=0 = the single pass. (Data parallel: the norm is over REDUCED gradients.)
-        self._early = (self.reducer is None and ranges is None and self.device.type == "cuda"
-                       and os.environ.get("MMSA_EARLY_SUMSQ", "1") != "0")
-        if self._early:
-            L = _lib.load()
-            self._slot_cap = 64
-            self._sumsq = torch.zeros(self._slot_cap, dtype=torch.float64, device=self.device)
-            self._sumsq_ws = torch.empty(self._slot_cap * int(L.mmsa_grad_norm_ws_bytes()), dtype=torch.uint8, device=self.device)
-            self._slots = 0
-            self._announced = 0
+        # (Round 4 measured taking each range's sum of squares the moment the backward announces it — 16 small launches under the
+        #  backward instead of one 540 MB pass behind it: 17.04 against 16.82 ms per step; the extra launches stretch the GEMMs they
+        #  run beside by more than the 0.09 ms they take out of the tail. Removed.)
         for e, off, n in self.state.ranges:
             on = self.reducer is not None
-            e._grad_ready_hook = self._on_grads_ready if on else (self._early_ready if self._early else None)
-            head = isinstance(e, HeadEngine)
-            e._grad_range_hook = (self._on_range_ready if on and not head else
-                                  (self._early_range if self._early and not head else None))
-
-    def _early_sumsq(self, start, length):
-        """Enqueue the sum of squares of grad[start, start + length) on the CURRENT stream (the one the range is complete on)."""
-        if length <= 0:
-            return
-        if self._slots >= self._slot_cap:
-            self._announced = -(1 << 60)  # more ranges than slots: this step falls back to the single pass
-            return
-        L = _lib.load()
-        k = self._slots
-        wsb = int(L.mmsa_grad_norm_ws_bytes())
-        offs, lens = (ctypes.c_int64 * 1)(int(start)), (ctypes.c_int64 * 1)(int(length))
-        check(L.mmsa_grad_sumsq_ranges(ptr(self.state.flat_g), offs, lens, 1, ptr(self._sumsq[k:k + 1]),
-                                       ptr(self._sumsq_ws[k * wsb:(k + 1) * wsb]), stream_ptr()), "mmsa_grad_sumsq_ranges")
-        self._slots += 1
-        self._announced += int(length)
-
-    def _early_range(self, eng, off, length):  # an encoder announces a range (mmsa_*_bwd_cb)
-        base, _n = self._ranges[id(eng)]
-        self._early_sumsq(base + off, length)
-
-    def _early_ready(self, eng):  # end of an engine's backward: a head's whole range (the encoders announced theirs piecewise)
-        if isinstance(eng, HeadEngine):
-            off, n = self._ranges[id(eng)]
-            self._early_sumsq(off, n)
+            e._grad_ready_hook = self._on_grads_ready if on else None
+            e._grad_range_hook = self._on_range_ready if on and not isinstance(e, HeadEngine) else None
 
     def _on_range_ready(self, eng, off, length):  # from inside the encoder's backward: a few layers / a stage at a time
         base, _n = self._ranges[id(eng)]
@@ -670,8 +627,6 @@ class FusedTrainStep:
             self.reducer.begin_step()
         for e, _, _ in self.state.ranges:
             e._overwrite_next = True  # every gradient range is written (not accumulated) by this backward
-        if self._early:
-            self._slots, self._announced = 0, 0
         logits, _aux = model(image, token_ids, attention_mask, labels)
         B, C = logits.shape
         dlogits = torch.empty_like(logits)
@@ -695,10 +650,6 @@ class FusedTrainStep:
             self.opt.set_shard_ranges(self.reducer.step_ranges(), self.reducer.norm_ranges())
             self.opt.step(1.0 / self.world, None, sumsq_group=True)
             self.reducer.gather(self.state, self.gather_dtype)
-        elif self._early and self._announced == self.state.flat_g.numel():
-            # every element was announced exactly once (the ranges tile the buffer): the partial sums are complete on streams this
-            # one has joined; only the finalize + AdamW are left
-            self.opt.step(1.0, self.loss, presummed=(self._sumsq, self._slots))
         else:
             self.opt.step(1.0 / self.world, self.loss if self.world == 1 else None)
         return self.loss, logits
