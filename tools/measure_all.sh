@@ -12,6 +12,8 @@ R=$GRAFT_REPO_ROOT
 echo "rocprof done"
 bash tools/run_pmc.sh
 echo "pmc done"
+bash tools/run_pmc_sq.sh > gpurun_out/${P}_pmc_sq.log 2>&1 || { tail -5 gpurun_out/${P}_pmc_sq.log; exit 1; }
+echo "pmc sq done"
 # rehearsal of the multi-rank path on the one GPU of the box (gloo moves the gradients; both ranks share cuda:0)
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --repeats 1 --backend gloo --no-cpu-baseline > gpurun_out/${P}_ddp2.log 2>&1 || { tail -20 gpurun_out/${P}_ddp2.log; exit 1; }
 tail -1 gpurun_out/${P}_ddp2.log | cut -c1-200

@@ -13,6 +13,8 @@ def family(name):
     n = name.split("(")[0].replace("void ", "")
     if "gemm2_kernel" in n:
         return "gemm2_kernel" + n[n.index("<"):] if "<" in n else n
+    if "gemm_stream" in n:  # the streaming convolution kernels (gemm_stream.hip): one family per instantiation
+        return n[n.index("gemm_stream"):]
     n = re.sub(r"<.*", "", n)
     m = re.match(r"_Z\d+([a-z_0-9]+?)(I|P|E|v).*", n)
     return m.group(1) if m else n
@@ -41,7 +43,7 @@ for k, c in per.items():
                  "active_inst_frac": c.get("SQ_ACTIVE_INST_ANY", 0.0) / wave})
 rows.sort(key=lambda r: -r["gui_cycles"])
 tot = sum(r["gui_cycles"] for r in rows)
-g = [r for r in rows if r["kernel"].startswith("gemm2_kernel")]
+g = [r for r in rows if r["kernel"].startswith("gemm2_kernel") or r["kernel"].startswith("gemm_stream")]
 gt = sum(r["gui_cycles"] for r in g)
 out = {"note": __doc__.split("usage")[0].strip(), "kernels": rows[:40],
        "all_gemm2": {"share_of_gpu_cycles": gt / tot if tot else None,

@@ -13,7 +13,7 @@ def agg(path, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        if "gemm2_kernel" not in name and "gemm_bf16_kernel" not in name:
+        if "gemm2_kernel" not in name and "gemm_bf16_kernel" not in name and "gemm_stream" not in name:
             continue
         key = (r["Dispatch_Id"], counter)
         if key in seen:

@@ -2,7 +2,7 @@
 # usage: tools/publish_profiles.sh <prefix in gpurun_out, e.g. r2z> [round tag, default r02]  — copies a measurement set into profiles/
 set -e
 P=$1
-R=${2:-r02}
+R=${2:-r04}
 C=$(git rev-parse --short HEAD)
 python3 - <<PY
 import json
