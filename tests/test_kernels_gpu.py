@@ -3,6 +3,8 @@
 References are computed on the CPU in float64 from the same (already storage-rounded) inputs, so the only
 differences are accumulation order and the final rounding to the storage type.
 """
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -15,6 +17,23 @@ from multimodal_sentiment_aanalysis_amd._lib import (ACT_GELU, ACT_NONE, ACT_REL
 
 IMPLS = [(GEMM_F32_SIMT, torch.float32), (GEMM_BF16_MFMA, torch.bfloat16), (GEMM_BF16_SIMT, torch.bfloat16),
          (GEMM_F32_MFMA, torch.float32)]
+
+
+class disabled:
+    """MMSA_DISABLE=<names> for the calls inside (the library reads the variable at every call)."""
+
+    def __init__(self, what):
+        self.what = what
+
+    def __enter__(self):
+        self.old = os.environ.get("MMSA_DISABLE")
+        os.environ["MMSA_DISABLE"] = self.what
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("MMSA_DISABLE", None)
+        else:
+            os.environ["MMSA_DISABLE"] = self.old
 
 
 def rnd(shape, dtype, dev, seed, scale=1.0):
@@ -150,7 +169,7 @@ def test_gemm_batch_rows(dev, dtype, impl, M, N, Kd, lay):
     assert_close(Cf, C0.cpu().double() + ref, f32 if dtype == f32 else torch.bfloat16, f"{lay} accumulate", k=Kd)
 
 
-@pytest.mark.parametrize("case", ["nt", "nn", "tn_split", "tn_kc", "edge", "epilogue"])
+@pytest.mark.parametrize("case", ["nt", "nt_k16", "nt_split", "nn", "tn_split", "tn_kc", "edge", "epilogue"])
 def test_gemm_f32_mfma_matches_valu_bitwise(dev, case):
     """The exact-fp32 matrix-core kernel (v_mfma_f32_32x32x2_f32, gemm_f32_mfma.hip) against the VALU-fma kernel: the MFMA
     is a k-ordered fmaf chain and both kernels use the same K order and split-K partition, so the results must be EQUAL
@@ -160,6 +179,14 @@ def test_gemm_f32_mfma_matches_valu_bitwise(dev, case):
         M, N, Kd = 1024, 768, 768
         A, B = rnd((M, Kd), f32, dev, 1), rnd((N, Kd), f32, dev, 2)
         run = lambda C, impl: K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, impl=impl)  # noqa: E731
+    elif case == "nt_k16":  # K a multiple of 16 only
+        M, N, Kd = 256, 384, 208
+        A, B = rnd((M, Kd), f32, dev, 1), rnd((N, Kd), f32, dev, 2)
+        run = lambda C, impl: K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, impl=impl)  # noqa: E731
+    elif case == "nt_split":  # split-K slabs, rows / columns past the tile edge
+        M, N, Kd = 200, 264, 2048
+        A, B = rnd((M, Kd), f32, dev, 1), rnd((N, Kd), f32, dev, 2)
+        run = lambda C, impl: K.gemm(A, B, C, M, N, Kd, Kd, Kd, N, out_f32=1, split_k=4, impl=impl)  # noqa: E731
     elif case == "nn":
         M, N, Kd = 512, 768, 3072
         A, B = rnd((M, Kd), f32, dev, 1), rnd((Kd, N), f32, dev, 2)
