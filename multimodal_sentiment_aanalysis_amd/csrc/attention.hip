@@ -55,9 +55,15 @@ __device__ __forceinline__ void stage_rows(unsigned char* img, const bf16* src, 
 #define MAX_TILES 16  // S <= 256 for the forward (scores of one query block live in registers)
 
 // ------------------------------------------------------------------------------------------------ MFMA forward
-template <int NT>  // NT = S / 16
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask,
-                                                            bf16* __restrict__ ctx, int S, int heads, float scale) {
+// NW waves per workgroup: 4 (64 queries) in general; 8 when S is a multiple of 128 — at S = 128 that is ONE workgroup per
+// (batch, head): K and V are staged once instead of twice, and with 60 registers per lane four 33 KiB workgroups fit a CU, so
+// B * heads = 768 workgroups are one round on the chip where 1536 four-wave workgroups took a round and a half. Same per-wave
+// code, bit-identical results; 21.3 -> 14.1 us at B = 64, S = 128 (47.2 -> 29.4 at B = 32, S = 256, 16 heads), tools/microbench/
+// bench_attn.py. (The same idea for the backward — K, V and Q, dO sharing two LDS images so that three workgroups fit a CU — was
+// measured and removed: 33.4 -> 49.4 us; the register-lean form it needs spills and the second staging is exposed.)
+template <int NT, int NW = 4>  // NT = S / 16
+__global__ __launch_bounds__(NW * 64, (NW == 8 && NT == 8) ? 6 : 1) void attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask,
+                                                                bf16* __restrict__ ctx, int S, int heads, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Hd = heads * HD, ld = 3 * Hd;
   const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
@@ -67,11 +73,11 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
   unsigned char* Vt = smem + S * 128;
   float* mb = (float*)(smem + 2 * S * 128);
   const bf16* base = qkv + (long)b * S * ld + h * HD;
-  stage_rows(Kt, base + Hd, ld, S, tid, 256);
-  stage_rows(Vt, base + 2 * Hd, ld, S, tid, 256);
-  for (int i = tid; i < S; i += 256) mb[i] = (mask == nullptr || mask[(long)b * S + i] != 0.f) ? 0.f : 1.f;
+  stage_rows(Kt, base + Hd, ld, S, tid, NW * 64);
+  stage_rows(Vt, base + 2 * Hd, ld, S, tid, NW * 64);
+  for (int i = tid; i < S; i += NW * 64) mb[i] = (mask == nullptr || mask[(long)b * S + i] != 0.f) ? 0.f : 1.f;
   __syncthreads();
-  const int q0 = (blockIdx.x * 4 + wave) * 16;
+  const int q0 = (blockIdx.x * NW + wave) * 16;
   if (q0 >= S) return;  // no barriers below
 
   bf16x8 qf[2];
@@ -928,6 +934,19 @@ static int attn_fwd_mfma_nt(const void* qkv, const float* mask, void* ctx, int B
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
+  }
+  if constexpr (NT % 8 == 0) {
+    if (!mmsa_disabled("attn_fwd8")) {
+      static bool attr8 = false;
+      if (!attr8) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr8 = true;
+      }
+      hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT, 8>), dim3(S / 128, B * heads), dim3(512), lds, st, (const bf16*)qkv, mask,
+                         (bf16*)ctx, S, heads, 0.125f);
+      MMSA_CHECK_LAUNCH();
+      return MMSA_OK;
+    }
   }
   dim3 grid(cdiv(S, 64), B * heads);
   hipLaunchKernelGGL(attn_fwd_mfma_kernel<NT>, grid, dim3(256), lds, st, (const bf16*)qkv, mask, (bf16*)ctx, S, heads,

@@ -438,11 +438,16 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
     if (r < M) y[(long)r * C + c] = apply_act(xs[i] * sc + sh, act);
   }
 }
+// drop_mask (or null): dy is the gradient behind a Dropout whose keep bytes these are — dropout_bwd_kernel's expression applied on
+// load. relu_in: x is relu(pre-activation) and dx is wanted at the pre-activation (Linear -> ReLU -> BatchNorm units) —
+// ew2d_kernel's EW_RELU_BWD applied on store. One launch instead of three for the fusion head's units.
 __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ dx, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate, int M, int C, int act) {
+                                                           float* __restrict__ dbeta, int accumulate, int M, int C, int act,
+                                                           const unsigned char* __restrict__ drop_mask, float drop_p,
+                                                           int relu_in) {
   __shared__ float rs[32][8], rq[32][8];
   const int cc = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cc;
   const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
@@ -457,7 +462,9 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     if (r < M) {
       const float xr = x[(long)r * C + c];
       xh[i] = (xr - mu) * is;
-      dz[i] = bn_dz1(dy[(long)r * C + c], xh[i], g, b, xr * sc + sh, act);
+      float d = dy[(long)r * C + c];
+      if (drop_mask) d = drop_mask[(long)r * C + c] ? d / (1.f - drop_p) : 0.f;
+      dz[i] = bn_dz1(d, xh[i], g, b, xr * sc + sh, act);
     }
     s += dz[i];
     q += dz[i] * xh[i];
@@ -476,7 +483,11 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < BN_SMALL_RPT; ++i) {
     const int r = rl + 32 * i;
-    if (r < M) dx[(long)r * C + c] = gi * (dz[i] - mb - xh[i] * mg);
+    if (r < M) {
+      const float v = gi * (dz[i] - mb - xh[i] * mg);
+      // (x = mu + xh / is exactly as loaded: the sign test reads the stored relu output again, cheap and exact)
+      dx[(long)r * C + c] = relu_in ? (x[(long)r * C + c] > 0.f ? v : 0.f) : v;
+    }
   }
 }
 static bool bn_small_ok(int dtype, int M, int training, const void* res, const void* mask) {
@@ -564,7 +575,7 @@ int bn_backward(int dtype, const void* dy, const void* x, const void* y, const f
   // (a saved output with ReLU means the forward may have added a residual: the streamed kernels read the sign from it)
   if (bn_small_ok(dtype, M, training, dres, relu_mask) && !(act == MMSA_ACT_RELU && y)) {
     hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C / 8), dim3(256), 0, st, (const float*)dy, (const float*)x, mean, invstd,
-                       gamma, beta, (float*)dx, dgamma, dbeta, accumulate, M, C, act);
+                       gamma, beta, (float*)dx, dgamma, dbeta, accumulate, M, C, act, (const unsigned char*)nullptr, 0.f, 0);
     MMSA_CHECK_LAUNCH();
     return MMSA_OK;
   }
@@ -573,4 +584,17 @@ int bn_backward(int dtype, const void* dy, const void* x, const void* y, const f
                                (bf16*)dres, dgamma, dbeta, accumulate, ws, M, C, act, training, st, relu_mask);
   return bn_backward_t<float>((const float*)dy, (const float*)x, (const float*)y, mean, invstd, gamma, beta, (float*)dx,
                               (float*)dres, dgamma, dbeta, accumulate, ws, M, C, act, training, st, relu_mask);
+}
+
+// The fusion head's unit backward up to its Linear: [Dropout backward ->] BatchNorm backward [-> ReLU backward] in one launch
+// (fp32, <= BN_SMALL_ROWS rows, training statistics); MMSA_ERR_UNSUPPORTED otherwise (the caller launches the separate kernels).
+int bn_small_backward_unit(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, float* dx, float* dgamma, float* dbeta, int accumulate, int M, int C, int act,
+                           int training, const unsigned char* drop_mask, float drop_p, int relu_in, hipStream_t st) {
+  if (C % 8 || M <= 0) return MMSA_ERR_ARG;
+  if (!bn_small_ok(MMSA_F32, M, training, nullptr, nullptr) || act == MMSA_ACT_RELU) return MMSA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C / 8), dim3(256), 0, st, dy, x, mean, invstd, gamma, beta, dx, dgamma, dbeta,
+                     accumulate, M, C, act, drop_mask, drop_p, relu_in);
+  MMSA_CHECK_LAUNCH();
+  return MMSA_OK;
 }

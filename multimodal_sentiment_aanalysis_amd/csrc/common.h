@@ -41,7 +41,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // problems need it anyway (a statistics pass where the convolution ran with a K split, one launch per weight gradient where the
 // group does not fit, ...); the parity tests compare the two forms in one process, so the variable is read at every call.
 // Names: conv_stats, parity_dgrad, bn_fold, bn_mask, bn_small, wgrad_defer, wgrad_group, bias_group, layer_group, group_order,
-// g2_2d, epi_spec, gelu_factor, fp8_ln_fuse, f32_tiny, bf16_tiny, attn_bwd_rc, stream1x1, stream3x3, ln_halfwave, pool8, defer_finalize.
+// g2_2d, epi_spec, gelu_factor, fp8_ln_fuse, f32_tiny, bf16_tiny, attn_bwd_rc, stream1x1, stream3x3, ln_halfwave, pool8, defer_finalize, head_units, attn_fwd8.
 #include <stdlib.h>
 #include <string.h>
 static inline bool mmsa_disabled(const char* name) {
@@ -116,6 +116,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case MMSA_ACT_SIGMOID: return sigmoidf_(v);
     default: return v;
   }
+}
+
+// Counter-based uniform in [0, 1) for Dropout (seed, element index): reproducible per step, the same value in whichever kernel
+// applies the Dropout (headops.hip's dropout_fwd_kernel, head_fused.hip's unit kernel)
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long i) {
+  unsigned long long z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
 // wave64 reductions

@@ -142,7 +142,22 @@ static LbgWs lbg_ws(Bump& b, int M, int n) {
   w.dyb = (float*)b.take((size_t)M * n * 4); w.dz = (float*)b.take((size_t)M * n * 4);
   return w;
 }
-static int lbg_fwd(const HCtx& h, const LinP& l, const BnP& bn, const float* x, long ldx, LbgWs& w, int M, int salt, const float** out) {
+// out2 (optional): a second destination of the unit's output; *copied says whether the launch wrote it (else the caller copies)
+static int lbg_fwd(const HCtx& h, const LinP& l, const BnP& bn, const float* x, long ldx, LbgWs& w, int M, int salt, const float** out,
+                   float* out2 = nullptr, bool* copied = nullptr) {
+  if (h.c.training && head_units_on()) {  // the whole unit as one launch (head_fused.hip)
+    UnitFwd f;
+    f.x = x; f.ldx = ldx; f.W = h.P(l.w); f.bias = h.P(l.b); f.gamma = h.P(bn.g); f.beta = h.P(bn.b);
+    f.rmean = h.bn + bn.rm; f.rvar = h.bn + bn.rv;
+    f.z = w.z; f.y = w.y; f.yd = h.drop() ? w.yd : nullptr; f.mask = h.drop() ? w.mask : nullptr; f.out2 = out2;
+    f.mean = w.mean; f.invstd = w.invstd;
+    f.M = M; f.N = l.out; f.lin_act = MMSA_ACT_NONE; f.bn_act = MMSA_ACT_GELU;
+    f.eps = h.c.bn_eps; f.momentum = h.c.bn_momentum; f.drop_p = h.c.dropout_p; f.seed = h.seed + 0x1000ull * salt;
+    const int rc = unit_fwd_fused(f, l.in, h.e.st);
+    if (rc == MMSA_OK) { *out = h.drop() ? w.yd : w.y; if (copied) *copied = out2 != nullptr; return MMSA_OK; }
+    if (rc != MMSA_ERR_UNSUPPORTED) return rc;
+  }
+  if (copied) *copied = false;
   RET_IF(h.lin_fwd(l, x, ldx, w.z, l.out, M));
   RET_IF(h.bn_fwd(bn, w.z, w.y, w.mean, w.invstd, M, MMSA_ACT_GELU));
   *out = w.y;
@@ -154,6 +169,13 @@ static int lbg_fwd(const HCtx& h, const LinP& l, const BnP& bn, const float* x, 
 }
 static int lbg_bwd(const HCtx& h, const LinP& l, const BnP& bn, const float* dy, const float* x, long ldx, LbgWs& w, float* dx,
                    long lddx, int M) {
+  if (head_units_on()) {  // Dropout backward + BatchNorm backward as one launch
+    const int rc = bn_small_backward_unit(dy, w.z, w.mean, w.invstd, h.P(bn.g), h.P(bn.b), w.dz, h.g ? h.G(bn.g) : nullptr,
+                                          h.g ? h.G(bn.b) : nullptr, h.acc, M, bn.c, MMSA_ACT_GELU, h.c.training,
+                                          h.drop() ? w.mask : nullptr, h.c.dropout_p, 0, h.e.st);
+    if (rc == MMSA_OK) return h.lin_bwd(l, w.dz, l.out, x, ldx, dx, lddx, M);
+    if (rc != MMSA_ERR_UNSUPPORTED) return rc;
+  }
   const float* d = dy;
   if (h.drop()) { RET_IF(dropout_bwd(dy, w.mask, w.dyb, (long)M * l.out, h.c.dropout_p, h.e.st)); d = w.dyb; }
   RET_IF(h.bn_bwd(bn, d, w.z, nullptr, w.mean, w.invstd, w.dz, M, MMSA_ACT_GELU));
@@ -171,6 +193,20 @@ static LrbWs lrb_ws(Bump& b, int M, int n) {
 }
 static int lrb_fwd(const HCtx& h, const LinP& l, const BnP& bn, const float* x, long ldx, LrbWs& w, int M, float drop_p, int salt,
                    const float** out, float* direct_out = nullptr) {
+  if (h.c.training && head_units_on()) {  // the whole unit as one launch (head_fused.hip)
+    const bool dr = drop_p > 0.f;
+    UnitFwd f;
+    f.x = x; f.ldx = ldx; f.W = h.P(l.w); f.bias = h.P(l.b); f.gamma = h.P(bn.g); f.beta = h.P(bn.b);
+    f.rmean = h.bn + bn.rm; f.rvar = h.bn + bn.rv;
+    f.z = w.r; f.y = (direct_out && !dr) ? direct_out : w.y; f.yd = dr ? (direct_out ? direct_out : w.yd) : nullptr;
+    f.mask = dr ? w.mask : nullptr; f.out2 = nullptr;
+    f.mean = w.mean; f.invstd = w.invstd;
+    f.M = M; f.N = l.out; f.lin_act = MMSA_ACT_RELU; f.bn_act = MMSA_ACT_NONE;
+    f.eps = h.c.bn_eps; f.momentum = h.c.bn_momentum; f.drop_p = drop_p; f.seed = h.seed + 0x1000ull * salt;
+    const int rc = unit_fwd_fused(f, l.in, h.e.st);
+    if (rc == MMSA_OK) { *out = dr ? f.yd : f.y; return MMSA_OK; }
+    if (rc != MMSA_ERR_UNSUPPORTED) return rc;
+  }
   RET_IF(h.lin_fwd(l, x, ldx, w.r, l.out, M, MMSA_ACT_RELU));
   float* y = (direct_out && !(h.c.training && drop_p > 0.f)) ? direct_out : w.y;
   RET_IF(h.bn_fwd(bn, w.r, y, w.mean, w.invstd, M, MMSA_ACT_NONE));
@@ -184,6 +220,14 @@ static int lrb_fwd(const HCtx& h, const LinP& l, const BnP& bn, const float* x, 
 }
 static int lrb_bwd(const HCtx& h, const LinP& l, const BnP& bn, const float* dy, const float* x, long ldx, LrbWs& w, float drop_p,
                    float* dx, long lddx, int M) {
+  if (head_units_on()) {  // Dropout backward + BatchNorm backward + ReLU backward as one launch
+    const bool dr = h.c.training && drop_p > 0.f;
+    const int rc = bn_small_backward_unit(dy, w.r, w.mean, w.invstd, h.P(bn.g), h.P(bn.b), w.dpre, h.g ? h.G(bn.g) : nullptr,
+                                          h.g ? h.G(bn.b) : nullptr, h.acc, M, bn.c, MMSA_ACT_NONE, h.c.training,
+                                          dr ? w.mask : nullptr, drop_p, 1, h.e.st);
+    if (rc == MMSA_OK) return h.lin_bwd(l, w.dpre, l.out, x, ldx, dx, lddx, M);
+    if (rc != MMSA_ERR_UNSUPPORTED) return rc;
+  }
   const float* d = dy;
   if (h.c.training && drop_p > 0.f) { RET_IF(dropout_bwd(dy, w.mask, w.dyb, (long)M * l.out, drop_p, h.e.st)); d = w.dyb; }
   RET_IF(h.bn_bwd(bn, d, w.r, nullptr, w.mean, w.invstd, w.dr, M, MMSA_ACT_NONE));
@@ -374,8 +418,9 @@ static int wh_fwd(const HCtx& h, const HeadLayout& L, HeadWs& w, const float* co
   RET_IF(weighted_concat_fwd(w.wl, in[0], in[3], in[4], w.wsm, w.wcat, B, E, e.st));
   const float *f1, *f2, *a1;
   RET_IF(lbg_fwd(h, L.fu0, L.fu1, w.wcat, 3 * E, w.fu0, B, 2, &f1));
-  RET_IF(lbg_fwd(h, L.fu4, L.fu5, f1, 256, w.fu4, B, 3, &f2));
-  RET_IF(ew2d(EW_COPY, f2, 128, nullptr, 0, out[1], 128, B, 128, e.st));
+  bool copied = false;
+  RET_IF(lbg_fwd(h, L.fu4, L.fu5, f1, 256, w.fu4, B, 3, &f2, out[1], &copied));
+  if (!copied) RET_IF(ew2d(EW_COPY, f2, 128, nullptr, 0, out[1], 128, B, 128, e.st));
   RET_IF(lbg_fwd(h, L.ar0, L.ar1, f2, 128, w.ar0, B, 4, &a1));
   RET_IF(h.lin_fwd(L.ar4, a1, 128, out[0], h.c.num_classes, B));
   if (h.c.valence) {

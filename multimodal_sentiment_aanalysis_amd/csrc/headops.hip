@@ -328,13 +328,6 @@ int ce_fwd_bwd(const float* logits, const long long* labels, float* loss, float*
 }
 
 // ------------------------------------------------------------------------------------------------ dropout
-__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long i) {
-  unsigned long long z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
 // y = x * keep / (1-p); mask saved as bytes. Counter-based (seed, element index): reproducible per step.
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ mask,
                                    long n, float p, unsigned long long seed) {

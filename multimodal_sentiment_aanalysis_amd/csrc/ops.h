@@ -77,6 +77,9 @@ int bn_forward(int dtype, const void* x, const float* gamma, const float* beta, 
 int bn_backward(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
                 const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
                 float* ws, int M, int C, int act, int training, hipStream_t st, const unsigned char* relu_mask = nullptr);
+int bn_small_backward_unit(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, float* dx, float* dgamma, float* dbeta, int accumulate, int M, int C, int act,
+                           int training, const unsigned char* drop_mask, float drop_p, int relu_in, hipStream_t st);
 // relu_mask (optional, act == RELU): [M][C/8] bytes, bit e of byte (m, c/8) = output (m, c+e) > 0. Written by the forward,
 // read by the backward instead of the saved output y (1/16 of its bytes in two streamed passes).
 
@@ -108,6 +111,25 @@ int mha_core_bwd(const float* q, long ldq, const float* k, long ldk, const float
                  int Lq, int Lk, int E, int heads, hipStream_t st);
 int seq_pool_fwd(const float* x, float* y, unsigned char* idx, int B, int L, int E, int mode, hipStream_t st);
 int seq_pool_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int L, int E, int mode, hipStream_t st);
+// head_fused.hip (MMSA_DISABLE=head_units: the separate launches)
+bool head_units_on();
+// Linear -> BatchNorm1d (training statistics over <= 256 rows) -> activation [-> Dropout] unit as one launch; K in {128, 256, 768},
+// N % 16 == 0, else MMSA_ERR_UNSUPPORTED (the caller launches the separate kernels)
+struct UnitFwd {
+  const float* x; long ldx;                 // [M][K]
+  const float *W, *bias;                    // [N][K], [N]
+  const float *gamma, *beta;
+  float *rmean, *rvar;                      // running statistics (or null)
+  float *z;                                 // the Linear's output after lin_act (what the BatchNorm backward reads)
+  float *y;                                 // bn_act(BatchNorm(z)) (or null when only the Dropout output is kept)
+  float *yd; unsigned char* mask;           // Dropout output + keep bytes (both null: no Dropout)
+  float *out2;                              // a second copy of the unit's final output (or null)
+  float *mean, *invstd;
+  int M, N, lin_act, bn_act;
+  float eps, momentum, drop_p;
+  unsigned long long seed;
+};
+int unit_fwd_fused(const UnitFwd& p, int K, hipStream_t st);
 int gate_mix_fwd(const float* g, const float* q, long ldq, const float* a, long lda, float* mix, int B, int E, hipStream_t st);
 int gate_mix_bwd(const float* dmix, const float* g, const float* q, long ldq, const float* a, long lda, float* dq, float* da,
                  float* dgpre, int B, int E, hipStream_t st);

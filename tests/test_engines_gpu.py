@@ -465,7 +465,7 @@ def _feat(B, seed, dev=None):
     return t if dev is None else t.to(dev)
 
 
-@pytest.mark.parametrize("B,Lk", [(16, 1), (5, 4), (64, 1)])
+@pytest.mark.parametrize("B,Lk", [(16, 1), (5, 4), (64, 1), (37, 1), (7, 1)])
 def test_cross_modal_transformer(dev, B, Lk):
     torch.manual_seed(0)
     m = mm.CrossModalTransformer()
@@ -553,6 +553,57 @@ def test_weighted_head(dev, train, B):
         for k in work:
             if k.endswith("running_var") or k.endswith("running_mean"):
                 assert rel_err(post[k], work[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("B", [64, 37])
+def test_head_units_one_launch_match_the_separate_launches(dev, monkeypatch, B):
+    """head_fused.hip's Linear -> BatchNorm1d -> activation -> Dropout unit (one launch) and the unit backward up to its Linear
+    (Dropout + BatchNorm [+ ReLU] backward in one launch) against the separate launches (MMSA_DISABLE=head_units), in training mode
+    with Dropout on: same counter-based keep decisions (seed, element index), the Linear summed in the batch-row kernel's order,
+    the statistics in bn_small_fwd_kernel's partition -> equal up to the contraction of a few fp32 expressions (1e-6)."""
+    from multimodal_sentiment_aanalysis_amd.engine import HeadEngine
+
+    class Head(mm.MultimodalTransformerModel.__mro__[1]):
+        kind = 2
+
+        def __init__(self):
+            super().__init__()
+            self._init_head()
+
+        def _base_cfg(self):
+            c = super()._base_cfg()
+            c.update(embed=256, num_classes=3, valence=1, dropout_p=0.3)
+            return c
+
+        def _out_dims(self):
+            return [3, 128, 3]
+
+    res = []
+    for off in ("", "head_units"):
+        monkeypatch.setenv("MMSA_DISABLE", off)
+        torch.manual_seed(0)
+        HeadEngine._seed_counter = 0
+        m = Head()
+        m.train(True)
+        m.to(dev)
+        dins = [_feat(B, 10 + i, dev).requires_grad_(True) for i in range(5)]
+        out = m._run(*dins)
+        wa, wv, wf = (torch.randn(B, n, generator=torch.Generator().manual_seed(s)).to(dev) for n, s in ((3, 1), (3, 2), (128, 3)))
+        ((out[0] * wa).sum() + (out[2] * wv).sum() + (out[1] * wf).sum()).backward()
+        res.append(([o.detach() for o in out], [t.grad for t in dins], _grads(m), cpu_state(m)))
+    monkeypatch.delenv("MMSA_DISABLE", raising=False)
+    (o1, d1, g1, s1), (o2, d2, g2, s2) = res
+    for a, b in zip(o1, o2):
+        assert rel_err(a, b) < 1e-6
+    assert (o1[1] == 0).float().mean().item() > 0.2  # the Dropout is on (fused features: 30 % zeros)
+    assert torch.equal(o1[1] == 0, o2[1] == 0)
+    for a, b in zip(d1, d2):
+        assert rel_err(a, b) < 2e-6
+    for n in g1:
+        assert rel_err(g1[n], g2[n]) < 2e-6, n
+    for k in s1:
+        if k.endswith("running_var") or k.endswith("running_mean"):
+            assert rel_err(s1[k], s2[k]) < 1e-6, k
 
 
 @pytest.mark.parametrize("pool", ["max", "mean"])

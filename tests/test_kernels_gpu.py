@@ -412,6 +412,19 @@ def test_attention(dev, impl, dtype, B, S, heads, masked):
     assert err < (3e-2 if dtype == torch.bfloat16 else 1e-4), f"attn bwd err {err}"
 
 
+@pytest.mark.parametrize("B,S,heads", [(3, 128, 12), (2, 256, 4)])
+def test_attention_forward_eight_wave_workgroups_match_four_wave(dev, B, S, heads):
+    """S % 128 == 0: 8 waves per workgroup (K / V staged once per 128 queries) against the 4-wave launch (MMSA_DISABLE=attn_fwd8):
+    the per-wave code is the same -> equal bits."""
+    qkv = rnd((B * S, 3 * heads * 64), torch.bfloat16, dev, 1)
+    mask = torch.ones(B, S, device=dev)
+    mask[:, S - 5:] = 0
+    a = K.attention_fwd(qkv, mask, B, S, heads)
+    with disabled("attn_fwd8"):
+        b = K.attention_fwd(qkv, mask, B, S, heads)
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,C,act,use_res", [(512, 64, ACT_RELU, False), (128, 64, ACT_RELU, True), (2048, 256, ACT_RELU, True),
                                              (32, 512, ACT_NONE, False), (8, 128, ACT_RELU, False), (16, 256, ACT_GELU, False),
