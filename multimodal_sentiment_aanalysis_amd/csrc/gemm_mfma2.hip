@@ -1220,6 +1220,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
 
 // ---- host side -------------------------------------------------------------------------------------------------
 
+#ifndef G2_PART  // (host-side planning lives in the main translation unit only: see the end of this file)
 static int g2_num_cus() {
   static int n = 0;
   if (!n) {
@@ -1285,6 +1286,7 @@ bool gemm2_eligible(const GemmParams& p) {
 
 thread_local int g2_last_plan[3] = {0, 0, 0};  // profiling only (gemm_mfma.hip): tile shape and K split of the latest launch
 
+#endif  // !G2_PART
 static inline int g2_epi_class(const GemmParams& p) {
   return (p.mul || p.add) ? 2 : (p.bias || p.C2 || p.act != MMSA_ACT_NONE || (p.out_f32 && p.accumulate)) ? 1 : 0;
 }
@@ -1307,6 +1309,7 @@ static inline int g2_epi_kind(const GemmParams& p) {
   return 1;
 }
 
+#ifndef G2_PART
 struct G2Plan { int wm, nj, split; };  // wave rows (4: 256-row tile, 2: 128-row tile), column tiles per wave, K split
 static inline int g2_bm(const G2Plan& pl) { return pl.wm * 64; }
 static inline int g2_bn(const G2Plan& pl) { return pl.nj * 16 * (8 / pl.wm); }
@@ -1416,6 +1419,7 @@ static G2Plan g2_plan(const GemmParams& p, int cus, size_t ws_bytes_avail) {
   return plan;
 }
 
+#endif  // !G2_PART
 template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8, int EPI>
 static int g2_launch_e(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
   static bool attr_set = false;
@@ -1461,6 +1465,22 @@ static int g2_launch_nj(const GemmParams& p, const G2Sched& s, int grid, hipStre
   if (p.a_kmajor && p.b_kmajor) return g2_launch_t<WM, NJ, true, true, 0>(p, s, grid, st);
   return g2_launch_t<WM, NJ, true, false, 0>(p, s, grid, st);
 }
+
+// ---- one translation unit per tile shape -------------------------------------------------------------------------------------------
+// This file is compiled six times (csrc/Makefile): once plain — the host side: planning, scheduling, the grouped launches, with the
+// five g2_launch_nj<WM, NJ> families as EXTERNAL functions — and once per family with -DG2_PART=<WM><NJ>, which compiles nothing but
+// that family's kernel instantiations and its launcher. As one translation unit the ~100 instantiations took 5-6 minutes on one
+// core while the other seven idled: the whole library build was this file.
+#ifdef G2_PART  // (G2_PART = 10 WM + NJ, G2_PART_NAME = g2_launch_nj_<WM><NJ>: both from the Makefile)
+int G2_PART_NAME(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
+  return g2_launch_nj<G2_PART / 10, G2_PART % 10>(p, s, grid, st);
+}
+#else
+int g2_launch_nj_44(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st);
+int g2_launch_nj_43(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st);
+int g2_launch_nj_42(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st);
+int g2_launch_nj_22(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st);
+int g2_launch_nj_21(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st);
 
 // p.split_k on entry: 1 = no split wanted; > 1 = upper bound chosen by the caller (needs p.ws with room for it)
 int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
@@ -1569,12 +1589,12 @@ int gemm2_launch(const GemmParams& pin, size_t ws_bytes_avail, hipStream_t st) {
 #endif
       rc = MMSA_ERR_UNSUPPORTED;
     }
-    else if (plan.nj == 4) rc = g2_launch_nj<4, 4>(p, s, grid, st);
-    else if (plan.nj == 3) rc = g2_launch_nj<4, 3>(p, s, grid, st);
-    else rc = g2_launch_nj<4, 2>(p, s, grid, st);
+    else if (plan.nj == 4) rc = g2_launch_nj_44(p, s, grid, st);
+    else if (plan.nj == 3) rc = g2_launch_nj_43(p, s, grid, st);
+    else rc = g2_launch_nj_42(p, s, grid, st);
   } else {
-    if (plan.nj == 2) rc = g2_launch_nj<2, 2>(p, s, grid, st);
-    else rc = g2_launch_nj<2, 1>(p, s, grid, st);
+    if (plan.nj == 2) rc = g2_launch_nj_22(p, s, grid, st);
+    else rc = g2_launch_nj_21(p, s, grid, st);
   }
   if (rc) return rc;
   if (s.split_k > 1) {
@@ -1771,12 +1791,12 @@ int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hip
   g2_last_plan[0] = plan.wm; g2_last_plan[1] = plan.nj; g2_last_plan[2] = plan.split;
   int rc;
   if (plan.wm == 4) {
-    if (plan.nj == 4) rc = g2_launch_nj<4, 4>(p, s, grid, st);
-    else if (plan.nj == 3) rc = g2_launch_nj<4, 3>(p, s, grid, st);
-    else rc = g2_launch_nj<4, 2>(p, s, grid, st);
+    if (plan.nj == 4) rc = g2_launch_nj_44(p, s, grid, st);
+    else if (plan.nj == 3) rc = g2_launch_nj_43(p, s, grid, st);
+    else rc = g2_launch_nj_42(p, s, grid, st);
   } else {
-    if (plan.nj == 2) rc = g2_launch_nj<2, 2>(p, s, grid, st);
-    else rc = g2_launch_nj<2, 1>(p, s, grid, st);
+    if (plan.nj == 2) rc = g2_launch_nj_22(p, s, grid, st);
+    else rc = g2_launch_nj_21(p, s, grid, st);
   }
   if (rc) return rc;
   if (plan.split > 1) {
@@ -1788,3 +1808,4 @@ int gemm2_launch_group(const GemmParams* probs, float* const* colsum, int n, hip
   }
   return MMSA_OK;
 }
+#endif  // !G2_PART
