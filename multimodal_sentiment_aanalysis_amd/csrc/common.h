@@ -41,7 +41,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // problems need it anyway (a statistics pass where the convolution ran with a K split, one launch per weight gradient where the
 // group does not fit, ...); the parity tests compare the two forms in one process, so the variable is read at every call.
 // Names: conv_stats, parity_dgrad, bn_fold, bn_mask, bn_small, wgrad_defer, wgrad_group, bias_group, layer_group, group_order,
-// g2_2d, epi_spec, gelu_factor, fp8_ln_fuse, f32_tiny, bf16_tiny, attn_bwd_rc, stream1x1, stream3x3, ln_halfwave, pool8, defer_finalize, head_units, attn_fwd8.
+// g2_2d, epi_spec, gelu_factor, fp8_ln_fuse, f32_tiny, bf16_tiny, attn_bwd_rc, stream1x1, stream3x3, ln_halfwave, pool8, defer_finalize, head_units, attn_fwd8, ds_rmw.
 #include <stdlib.h>
 #include <string.h>
 static inline bool mmsa_disabled(const char* name) {

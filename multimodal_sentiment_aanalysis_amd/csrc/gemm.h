@@ -99,6 +99,11 @@ struct GemmParams {
   int c_gw, c_gh;
   long c_imgpitch, c_rowpitch, c_colpitch;
   FastDiv fd_c_ghw, fd_c_gw;
+  // c_rmw (with a row map; NN problems): the mapped rows are ADDED to what is stored there (fp32 add of the accumulator and the
+  // stored bf16 value, rounded once) instead of overwriting a zero-filled buffer: the strided 1x1 data gradient lands on top of the
+  // block's main-path data gradient, which was written first — no zero fill, and the main path's GEMM reads no side operand
+  // that is 3/4 zeros.
+  int c_rmw;
 };
 
 // element offset of filter tap (ky, kx) in the k-major weight view of a gather = 1 data gradient

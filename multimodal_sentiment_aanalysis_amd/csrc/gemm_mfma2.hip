@@ -504,6 +504,49 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmParams p, G2Sched s) 
       }
       return BIG ? 4 : 2;
     }
+    if constexpr (EPI == 6) {
+      // mapped read-modify-write (GemmParams::c_rmw): per pair of row tiles, load what is stored at the mapped rows in the store
+      // layout (16 bytes = 8 columns of one row per lane), bring it into the accumulator layout with the same lane swap the
+      // store uses (an involution), add in fp32, then the plain bf16 store. Not a counted epilogue (three launches per step).
+      const int mrow = mb + ((g4 & 1) << 4), ncol = C.n0 + wn * (NJ * 16) + ((g4 >> 1) << 3);
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        const int m = mrow + i * 16;
+        const uint32_t img = fd_div((uint32_t)m, p.fd_c_ghw);
+        const uint32_t rem = (uint32_t)m - img * (uint32_t)(p.c_gh * p.c_gw);
+        const uint32_t yy = fd_div(rem, p.fd_c_gw), xx = rem - yy * (uint32_t)p.c_gw;
+        const long rowoff = (long)img * p.c_imgpitch + (long)yy * p.c_rowpitch + (long)xx * p.c_colpitch;
+        i32x4 old[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int n = ncol + j * 16;
+          old[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, (m < eM && n < eN) ? (int)((rowoff + n) * 2) : OOB, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vm<0>();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int n = ncol + j * 16;
+          const auto o0 = __builtin_amdgcn_permlane16_swap((unsigned)old[j][0], (unsigned)old[j][2], false, false);
+          const auto o1 = __builtin_amdgcn_permlane16_swap((unsigned)old[j][1], (unsigned)old[j][3], false, false);
+          const bf16x4 ox = __builtin_bit_cast(bf16x4, i32x2{(int)o0[0], (int)o1[0]});
+          const bf16x4 oy = __builtin_bit_cast(bf16x4, i32x2{(int)o0[1], (int)o1[1]});
+          f32x4 x = acc[i][j], y = acc[i + 1][j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { x[e] += (float)ox[e]; y[e] += (float)oy[e]; }
+          const bf16x4 xb = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
+          const bf16x4 yb = {(bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
+          const i32x2 xi = __builtin_bit_cast(i32x2, xb), yi = __builtin_bit_cast(i32x2, yb);
+          const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)xi[0], (unsigned)yi[0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)xi[1], (unsigned)yi[1], false, false);
+          const i32x4 d = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+          __builtin_amdgcn_raw_buffer_store_b128(d, rsrcC, (m < eM && n < eN) ? (int)((rowoff + n) * 2) : OOB, 0, 0);
+        }
+      }
+      wait_vm<0>();
+      return 0;
+    }
     if (s.fast) {
       if (p.out_f32) {
 #pragma unroll
@@ -1435,6 +1478,12 @@ static int g2_launch_e(const GemmParams& p, const G2Sched& s, int grid, hipStrea
 }
 template <int WM, int NJ, bool A_KM, bool B_KM, int GATHER, bool FP8 = false>
 static int g2_launch_t(const GemmParams& p, const G2Sched& s, int grid, hipStream_t st) {
+  if (p.c_gw > 0 && p.c_rmw) {  // mapped read-modify-write store: the strided 1x1 data gradient (NN) on top of the main path's
+    if constexpr (!A_KM && B_KM && GATHER == 0 && !FP8 && NJ != 8) {
+      if (s.split_k == 1) return g2_launch_e<WM, NJ, A_KM, B_KM, GATHER, FP8, 6>(p, s, grid, st);
+    }
+    return MMSA_ERR_UNSUPPORTED;
+  }
   // plain-store and slab-store launches: the instantiation without the general epilogue (see gemm2_kernel)
   if (s.fast || s.split_k > 1) return g2_launch_e<WM, NJ, A_KM, B_KM, GATHER, FP8, 0>(p, s, grid, st);
   // the specialised epilogues exist for the plain (no gather, bf16 operands) NT and NN problems: the Linears of the text encoder

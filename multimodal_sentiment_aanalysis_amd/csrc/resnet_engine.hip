@@ -244,24 +244,43 @@ static int conv_fwd(const ResCtx& r, const ConvDef& c, const void* x, void* z, C
   }
   return r.e.gemm(p);
 }
+// Strided 1x1 data gradient (the downsample branch) as a dense GEMM over the Hout*Wout output-gradient rows whose epilogue
+// scatters each row to its pixel (s*y, s*x) (GemmParams c_gw..c_colpitch): is that form available for this convolution?
+static bool strided1x1_params(const ResCtx& r, const ConvDef& c, const void* dz, void* dx, GemmParams* out) {
+  if (!(c.k == 1 && c.stride > 1 && c.pad == 0 && r.c.dtype == MMSA_BF16 && !Eng::force_simt() && !Eng::v1_only() &&
+        c.Hin == c.Hout * c.stride && c.Win == c.Wout * c.stride))
+    return false;
+  GemmParams p = Eng::blank();
+  p.A = dz; p.lda = c.Cout; p.B = r.W(c.w); p.ldb = c.Cin; p.b_kmajor = 1; p.C = dx; p.ldc = c.Cin;
+  p.M = r.c.batch * c.Hout * c.Wout; p.N = c.Cin; p.K = c.Cout;
+  p.c_gw = c.Wout; p.c_gh = c.Hout;
+  p.c_imgpitch = (long)c.Hin * c.Win * c.Cin;
+  p.c_rowpitch = (long)c.stride * c.Win * c.Cin;
+  p.c_colpitch = (long)c.stride * c.Cin;
+  p.fd_c_ghw = make_fastdiv((uint32_t)(c.Hout * c.Wout));
+  p.fd_c_gw = make_fastdiv((uint32_t)c.Wout);
+  if (!gemm2_eligible(p)) return false;
+  *out = p;
+  return true;
+}
+// ... ADDED to what dx already holds at those pixels (GemmParams::c_rmw): the block's main-path data gradient is written first, the
+// projected-skip gradient lands on top of it — no zero fill of dx, no 3/4-zero side operand for the main path's GEMM.
+// MMSA_ERR_UNSUPPORTED: the form does not exist for this convolution (the caller takes the zero-fill + side-operand order).
+static int strided1x1_dgrad_onto(const ResCtx& r, const ConvDef& c, const void* dz, void* dx) {
+  static const bool off = mmsa_disabled("ds_rmw");
+  GemmParams p;
+  if (off || !strided1x1_params(r, c, dz, dx, &p)) return MMSA_ERR_UNSUPPORTED;
+  p.c_rmw = 1;
+  return gemm_bf16_launch(p, r.e.st);
+}
 // dx[B*Hi*Wi][Cin] = conv_transpose(dz) (+ add)
 static int conv_dgrad(const ResCtx& r, const ConvDef& c, const void* dz, void* dx, const void* add) {
   const int B = r.c.batch, M = B * c.Hin * c.Win, K = c.k * c.k * c.Cout;
-  // Strided 1x1 (the downsample branch): only the pixels (s*y, s*x) receive gradient. As a row gather over all
-  // Hin*Win pixels 3/4 of the MFMA rows multiply zeros; instead: zero-fill dx, then a dense GEMM over the Hout*Wout
-  // output-gradient rows whose plain-store epilogue scatters each row to its pixel (GemmParams c_gw..c_colpitch).
-  if (c.k == 1 && c.stride > 1 && c.pad == 0 && !add && r.c.dtype == MMSA_BF16 && !Eng::force_simt() && !Eng::v1_only() &&
-      c.Hin == c.Hout * c.stride && c.Win == c.Wout * c.stride) {
-    GemmParams p = Eng::blank();
-    p.A = dz; p.lda = c.Cout; p.B = r.W(c.w); p.ldb = c.Cin; p.b_kmajor = 1; p.C = dx; p.ldc = c.Cin;
-    p.M = B * c.Hout * c.Wout; p.N = c.Cin; p.K = c.Cout;
-    p.c_gw = c.Wout; p.c_gh = c.Hout;
-    p.c_imgpitch = (long)c.Hin * c.Win * c.Cin;
-    p.c_rowpitch = (long)c.stride * c.Win * c.Cin;
-    p.c_colpitch = (long)c.stride * c.Cin;
-    p.fd_c_ghw = make_fastdiv((uint32_t)(c.Hout * c.Wout));
-    p.fd_c_gw = make_fastdiv((uint32_t)c.Wout);
-    if (gemm2_eligible(p)) {
+  // Strided 1x1 on its own: only the pixels (s*y, s*x) receive gradient. As a row gather over all Hin*Win pixels 3/4 of the MFMA
+  // rows multiply zeros; instead: zero-fill dx, then the dense GEMM with the scattering plain-store epilogue.
+  if (!add) {
+    GemmParams p;
+    if (strided1x1_params(r, c, dz, dx, &p)) {
       if (hipMemsetAsync(dx, 0, (size_t)M * c.Cin * r.es, r.e.st) != hipSuccess) return MMSA_ERR_LAUNCH;
       return gemm_bf16_launch(p, r.e.st);
     }
@@ -677,9 +696,17 @@ int mmsa_resnet_bwd_cb2(const mmsa_resnet_cfg* cp, const float* w32, const void*
       RET_IF(bn_bwd(r, bd.ds, bw.ds, t2, nullptr, dzd, nullptr, MMSA_ACT_NONE, ws.bnws, wg));  // dzd
       if (wg) RET_IF(wgrad(bd.ds, dzd, xin));
       if (!last_needed) {
-        RET_IF(conv_dgrad(r, bd.ds, dzd, dOut, nullptr));  // dOut is free: holds the projected-skip data gradient
-        skip = dOut;
-        RET_IF(conv_dgrad(r, bd.c1, dz1, t2, skip));       // dx -> t2
+        GemmParams probe;
+        static const bool rmw_off = mmsa_disabled("ds_rmw");
+        if (!rmw_off && strided1x1_params(r, bd.ds, dzd, t2, &probe)) {
+          // main path first (plain store), then the strided projection's gradient added onto its pixels
+          RET_IF(conv_dgrad(r, bd.c1, dz1, t2, nullptr));    // dx -> t2
+          RET_IF(strided1x1_dgrad_onto(r, bd.ds, dzd, t2));
+        } else {
+          RET_IF(conv_dgrad(r, bd.ds, dzd, dOut, nullptr));  // dOut is free: holds the projected-skip data gradient
+          skip = dOut;
+          RET_IF(conv_dgrad(r, bd.c1, dz1, t2, skip));       // dx -> t2
+        }
         void* t = dOut; dOut = t2; t2 = t;
       }
     } else if (!last_needed) {

@@ -331,6 +331,34 @@ def test_resnet_strided_dgrad_parity_classes(dev, monkeypatch):
     _check_grads(ga, gb, 2e-2, "parity-class dgrad vs row gather", l2=True)
 
 
+@pytest.mark.parametrize("rcfg,B,HW", [(MINI_RESNET, 4, 96), (dict(blocks=(3, 4, 6, 3), widths=(64, 128, 256, 512)), 4, 128)])
+def test_resnet_strided_projection_gradient_added_onto_the_main_path(dev, monkeypatch, rcfg, B, HW):
+    """The first block of stages 2-4: the strided 1x1 projection's data gradient is ADDED onto the main path's data gradient at its
+    pixels by the GEMM's mapped read-modify-write epilogue (GemmParams::c_rmw; no zero fill, no 3/4-zero side operand) against the
+    zero-fill + side-operand order (MMSA_DISABLE=ds_rmw): same forward, same sums with the bf16 rounding point on the other addend
+    (round(acc_ds + bf16(acc_main)) instead of round(acc_main + bf16(acc_ds)) on a quarter of the pixels): the gradients agree to
+    bf16 resolution; what no strided projection's backward precedes (the tail, the last stage's last block) is untouched."""
+
+    def run(off):
+        monkeypatch.setenv("MMSA_DISABLE", off)
+        net, sd, ocfg, image, wgt = _resnet_case(rcfg, B, HW, dev)
+        net.to(dev).train()
+        out = net(image.to(dev))
+        (out * wgt.to(dev)).sum().backward()
+        return out.detach().float().cpu(), _grads(net)
+
+    out_a, g_a = run("")
+    out_b, g_b = run("ds_rmw")
+    monkeypatch.delenv("MMSA_DISABLE", raising=False)
+    assert torch.equal(out_a, out_b)
+    _check_grads(g_a, g_b, 2e-2, "projection gradient added in place vs zero fill + side operand", l2=True)
+    last = "resnet.layer4.%d." % (rcfg["blocks"][3] - 1)
+    same = [n for n in g_a if n.startswith("proj.") or n.startswith(last)]
+    assert same
+    for n in same:
+        assert torch.equal(g_a[n], g_b[n]), n
+
+
 @pytest.mark.parametrize("rcfg,B,HW", [(MINI_RESNET, 4, 96), (dict(blocks=(3, 4, 6, 3), widths=(64, 128, 256, 512)), 8, 128)])
 def test_resnet_weight_gradients_grouped_per_stage(dev, monkeypatch, rcfg, B, HW):
     """The weight gradients of a stage deferred to its end and launched in groups with one common K split (Eng::wgrad_batch ->
